@@ -1,0 +1,98 @@
+/* gmr_blob.h -- wire format of the packed robot + IK-config "model blob".
+ *
+ * One contiguous little-endian buffer: a fixed header followed by 8-byte
+ * aligned arrays.  It is what the host packs from an MJCF model and an
+ * ik_configs JSON file, what rank 0 broadcasts to the other GPUs, and what
+ * both the HIP library (include/gmr_amd.h) and the CPU oracle (oracle/) parse.
+ *
+ * It carries exactly the data the reference keeps in
+ *   - mujoco.MjModel (kinematic subset)      reference motion_retarget.py:27
+ *   - KinematicsModel tensors                reference kinematics_model.py:76-99
+ *   - the ik_config tables / offsets / scale reference motion_retarget.py:36-54,80-114
+ */
+#ifndef GMR_BLOB_H
+#define GMR_BLOB_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GMR_BLOB_MAGIC 0x42524D47u /* "GMRB" */
+#define GMR_BLOB_VERSION 1u
+
+#define GMR_JNT_NONE 0
+#define GMR_JNT_HINGE 1
+#define GMR_JNT_FREE 2
+
+#define GMR_MAX_BODIES 64 /* one body per lane in the IK kernel */
+#define GMR_MAX_TASKS 32  /* per table */
+#define GMR_MAX_SLOTS 32  /* distinct human bodies consumed */
+
+typedef struct gmr_blob_header {
+  uint32_t magic;
+  uint32_t version;
+  uint32_t total_bytes;
+  uint32_t reserved0;
+
+  int32_t nbody;      /* bodies, depth-first order, body 0 = free-joint root   */
+  int32_t nq;         /* 7 + hinges                                            */
+  int32_t nv;         /* 6 + hinges                                            */
+  int32_t nslot;      /* human bodies kept by scale_human_data (scale table)   */
+  int32_t ntask[2];   /* tasks with non-zero weight in table 1 / table 2       */
+  int32_t use_table[2];
+  int32_t root_slot;  /* slot of human_root_name                               */
+  int32_t reserved1[3];
+
+  /* byte offsets from the start of the blob */
+  uint32_t off_parent;        /* int32 [nbody]                                 */
+  uint32_t off_jnt_type;      /* int32 [nbody]  GMR_JNT_*                      */
+  uint32_t off_qpos_adr;      /* int32 [nbody]  -1 if none                     */
+  uint32_t off_dof_adr;       /* int32 [nbody]  -1 if none                     */
+  uint32_t off_jnt_limited;   /* int32 [nbody]                                 */
+  uint32_t off_body_pos;      /* f64 [nbody][3]                                */
+  uint32_t off_body_quat;     /* f64 [nbody][4] wxyz, unit (MuJoCo compile)    */
+  uint32_t off_body_quat_raw; /* f64 [nbody][4] wxyz, as written in the XML    */
+  uint32_t off_jnt_axis;      /* f64 [nbody][3] unit                           */
+  uint32_t off_jnt_range;     /* f64 [nbody][2] radians                        */
+  uint32_t off_qpos0;         /* f64 [nq]                                      */
+  uint32_t off_slot_scale;    /* f64 [nslot]   human_scale_table * height ratio*/
+  uint32_t off_slot_pos_off;  /* f64 [nslot][3] table-1 pos_offset - ground*z  */
+  uint32_t off_slot_rot_off;  /* f64 [nslot][4] table-1 rot_offset wxyz, unit  */
+  uint32_t off_slot_is_foot;  /* int32 [nslot] name contains "Foot"/"foot"     */
+  uint32_t off_task_body[2];  /* int32 [ntask[k]] robot body index             */
+  uint32_t off_task_slot[2];  /* int32 [ntask[k]] slot index                   */
+  uint32_t off_task_wp[2];    /* f64 [ntask[k]] position_cost                  */
+  uint32_t off_task_wr[2];    /* f64 [ntask[k]] orientation_cost               */
+  uint32_t reserved2[3];
+} gmr_blob_header;
+
+/* One unit of IK work: a run of consecutive frames of one clip, processed in
+ * time order with warm start.  The first n_burn frames only warm the state up
+ * (no output); the following n_out frames write qpos_out[frame].
+ * init_row >= 0 starts from qpos_init[init_row], otherwise from qpos0
+ * (reference: a fresh GeneralMotionRetargeting per clip, motion_retarget.py:75). */
+typedef struct gmr_work_item {
+  int64_t frame_begin; /* first frame processed (burn-in included)            */
+  int32_t n_burn;
+  int32_t n_out;
+  int32_t init_row;    /* row of qpos_init, or -1                              */
+  int32_t final_row;   /* row of qpos_final to receive the last state, or -1   */
+} gmr_work_item;
+
+/* Solver constants; defaults are the reference's hard-coded values. */
+typedef struct gmr_ik_params {
+  double damping;         /* 0.5    motion_retarget.py:19  (Tikhonov on dq)    */
+  double tol;             /* 1e-3   motion_retarget.py:153,172                 */
+  double limit_gain;      /* 0.95   mink ConfigurationLimit default            */
+  double lm_damping;      /* 1.0    motion_retarget.py:88,105                  */
+  int32_t max_iter;       /* 10     motion_retarget.py:56                      */
+  int32_t offset_to_ground; /* 0    motion_retarget.py:122,252-270             */
+  int32_t reserved[2];
+} gmr_ik_params;
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMR_BLOB_H */

@@ -1,0 +1,227 @@
+"""CPU-only checks that pin the oracle (oracle/gmr_oracle.c).
+
+FK (KinematicsModel convention) is pinned by golden vectors generated from the
+reference's own kinematics_model.py (tests/golden/make_golden.py).  The IK side has no
+runnable reference (mink/mujoco/daqp absent -> "parity unpinned"); it is pinned here by
+mathematical invariants: finite-difference Jacobians, KKT + an independent bounded
+least-squares solve, reachable-target recovery, limit behaviour, error1 == error2.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+from scipy.optimize import lsq_linear
+
+from gmr_amd import synth
+from oracle.oracle import IKParams, Oracle, WORK_ITEM_DTYPE, box_qp
+from tests.util import CONFIG_ROBOTS, compiled, make_items, quat_angle
+
+GOLDEN_ROBOTS = ["unitree_g1", "unitree_g1_with_hands", "booster_t1", "stanford_toddy", "fourier_n1"]
+
+
+@pytest.mark.parametrize("robot", GOLDEN_ROBOTS)
+def test_tree_matches_reference(robot, golden_dir):
+    cm = compiled("smplx", robot)
+    with open(os.path.join(golden_dir, f"tree_{robot}.json")) as f:
+        ref = json.load(f)
+    rob = cm.robot
+    assert rob.body_names == ref["body_names"]
+    assert rob.parent.tolist() == ref["parent_indices"]
+    dof_idx = [(-1 if rob.qpos_adr[b] < 7 else int(rob.qpos_adr[b] - 7)) for b in range(rob.nbody)]
+    assert dof_idx == ref["joint_dof_idx"]
+    lo, hi = rob.dof_limits()
+    np.testing.assert_allclose(lo.astype(np.float32), np.array(ref["lower"], np.float32), rtol=0, atol=0)
+    np.testing.assert_allclose(hi.astype(np.float32), np.array(ref["upper"], np.float32), rtol=0, atol=0)
+    assert rob.nq - 7 == ref["num_dof"]
+
+
+@pytest.mark.parametrize("robot", GOLDEN_ROBOTS)
+def test_fk_kin_matches_reference_golden(robot, golden_dir):
+    """oracle_fk_kin vs reference KinematicsModel.forward_kinematics; float32, tol 2e-6 (abs, metres / quat units)."""
+    cm = compiled("smplx", robot)
+    g = np.load(os.path.join(golden_dir, f"fk_{robot}.npz"))
+    orc = Oracle(cm.blob)
+    bp, br = orc.fk_kin(g["root_pos"], g["root_rot"], g["dof_pos"])
+    assert np.abs(bp - g["body_pos"]).max() < 2e-6 * max(1.0, np.abs(g["body_pos"]).max())
+    assert np.abs(br - g["body_rot"]).max() < 2e-6
+    T = g["dof_pos"].shape[0]
+    ident = np.tile(np.array([[0, 0, 0, 1]], np.float32), (T, 1))
+    bp0, _ = orc.fk_kin(np.zeros((T, 3), np.float32), ident, g["dof_pos"])
+    assert np.abs(bp0 - g["local_body_pos"]).max() < 2e-6
+
+
+def test_quat_mul_convention(golden_dir):
+    """wxyz Hamilton product agrees with reference rot_utils.quat_mul_np (golden)."""
+    g = np.load(os.path.join(golden_dir, "quat_mul_wxyz.npz"))
+    np.testing.assert_allclose(synth.qmul(g["a"], g["b"]), g["ab"], atol=1e-14)
+
+
+@pytest.mark.parametrize("robot", CONFIG_ROBOTS)
+def test_fk_mj_vs_fk_kin_conventions_agree(robot):
+    """MuJoCo-convention f64 FK == KinematicsModel-convention f32 FK up to f32 rounding and
+    the un-normalised XML quaternions the latter keeps (<= 5e-5 m on these models)."""
+    cm = compiled("smplx", robot)
+    orc = Oracle(cm.blob)
+    rng = np.random.default_rng(3)
+    q = synth.synth_robot_trajectory(cm.robot, 8, rng)
+    for f in range(8):
+        xp, xq = orc.fk_mj(q[f])
+        xp2, xq2 = synth.fk_numpy(cm.robot, q[f:f + 1])
+        assert np.abs(xp - xp2[0]).max() < 1e-12
+        root_xyzw = q[f, [4, 5, 6, 3]]
+        bp, _ = orc.fk_kin(q[f:f + 1, :3], root_xyzw[None], q[f:f + 1, 7:])
+        assert np.abs(bp[0] - xp).max() < 5e-5
+
+
+@pytest.mark.parametrize("robot", ["unitree_g1", "engineai_pm01", "unitree_g1_with_hands"])
+def test_task_jacobian_finite_difference(robot):
+    """J = d e / d dq: central differences of e(q (+) h e_k) vs the analytic J, all task bodies."""
+    cm = compiled("smplx", robot)
+    orc = Oracle(cm.blob)
+    rng = np.random.default_rng(5)
+    q = synth.synth_robot_trajectory(cm.robot, 4, rng)[3]
+    h = 1e-6
+    worst = 0.0
+    for body in cm.task_body[0]:
+        tp = rng.normal(0, 0.5, 3) + q[:3]
+        tq = rng.normal(size=4)
+        tq /= np.linalg.norm(tq)
+        e0, J = orc.task_error_and_jacobian(q, body, tp, tq)
+        Jfd = np.zeros_like(J)
+        for k in range(orc.nv):
+            dq = np.zeros(orc.nv)
+            dq[k] = h
+            ep, _ = orc.task_error_and_jacobian(orc.integrate(q, dq), body, tp, tq)
+            em, _ = orc.task_error_and_jacobian(orc.integrate(q, -dq), body, tp, tq)
+            Jfd[:, k] = (ep - em) / (2 * h)
+        worst = max(worst, np.abs(J - Jfd).max())
+    assert worst < 2e-6, worst
+
+
+def _kkt(H, c, lo, hi, x):
+    g = H @ x + c
+    r = 0.0
+    for i in range(len(x)):
+        at_lo, at_hi = abs(x[i] - lo[i]) < 1e-12, abs(x[i] - hi[i]) < 1e-12
+        if at_lo and not at_hi:
+            r = max(r, max(0.0, -g[i]))
+        elif at_hi and not at_lo:
+            r = max(r, max(0.0, g[i]))
+        elif not at_lo and not at_hi:
+            r = max(r, abs(g[i]))
+    return r
+
+
+def test_box_qp_random_vs_bvls():
+    rng = np.random.default_rng(7)
+    for trial in range(40):
+        n = int(rng.integers(3, 40))
+        A = rng.normal(size=(n + 5, n))
+        H = A.T @ A + 0.5 * np.eye(n)
+        c = rng.normal(size=n) * 10
+        lo = -np.abs(rng.normal(size=n)) * 0.2
+        hi = np.abs(rng.normal(size=n)) * 0.2
+        if trial % 5 == 0:  # some boxes that exclude 0
+            lo[0], hi[0] = 0.05, 0.3
+        x, _ = box_qp(H, c, lo, hi)
+        assert np.all(x >= lo - 1e-12) and np.all(x <= hi + 1e-12)
+        assert _kkt(H, c, lo, hi, x) < 1e-8 * (1 + np.abs(c).max())
+        L = np.linalg.cholesky(H)
+        ref = lsq_linear(L.T, -np.linalg.solve(L, c), bounds=(lo, hi), method="bvls", tol=1e-14).x
+        np.testing.assert_allclose(x, ref, atol=1e-8)
+
+
+@pytest.mark.parametrize("robot", CONFIG_ROBOTS)
+def test_reachable_targets_recovered(robot):
+    """Targets generated by FK of an in-limit trajectory are tracked: final error small,
+    qpos recovered within 1e-3 rad after the first frames, error1 == error2 at the truth."""
+    cm = compiled("smplx", robot)
+    orc = Oracle(cm.blob)
+    pos, quat, names, offs, qtrue = synth.synth_clips(cm, 1, 60, seed=11, dtype=np.float64, amp=0.2)
+    sc = cm.slot_columns(names)
+    q, iters, _ = orc.ik_solve(pos, quat, sc, make_items(offs, WORK_ITEM_DTYPE))
+    assert iters.min() >= 2 and iters.max() <= 22
+    active = np.zeros(cm.robot.nq, bool)  # coordinates some task constrains
+    for b in cm.task_body[0]:
+        while b >= 0:
+            a = cm.robot.qpos_adr[b]
+            if a >= 7:
+                active[a] = True
+            b = cm.robot.parent[b]
+    d = q[20:] - qtrue[20:]
+    assert np.abs(d[:, :3]).max() < 1e-3
+    assert quat_angle(q[20:, 3:7], qtrue[20:, 3:7]).max() < 1e-3
+    assert np.abs(d[:, active]).max() < 1e-3, np.abs(d[:, active]).max()
+    tp, tq = orc.prepare_targets(pos[30][sc], quat[30][sc])
+    e1, _ = orc.stage_error(0, qtrue[30], tp, tq, len(cm.tasks[0]))
+    e2, _ = orc.stage_error(1, qtrue[30], tp, tq, len(cm.tasks[1]))
+    assert e1 < 1e-9 and e2 < 1e-9
+
+
+def test_hand_dofs_stay_zero():
+    """unitree_g1_with_hands reuses the 29-DoF config: untasked hand hinges get zero gradient."""
+    cm = compiled("smplx", "unitree_g1_with_hands")
+    cm29 = compiled("smplx", "unitree_g1")
+    orc = Oracle(cm.blob)
+    pos, quat, names, offs, _ = synth.synth_clips(cm29, 1, 12, seed=2, hard=True, dtype=np.float64)
+    q, _, _ = orc.ik_solve(pos, quat, cm.slot_columns(names), make_items(offs, WORK_ITEM_DTYPE))
+    tasked = set()
+    for b in cm.task_body[0]:
+        while b >= 0:
+            tasked.add(int(b))
+            b = cm.robot.parent[b]
+    hand = [cm.robot.qpos_adr[b] for b in cm.robot.hinge_bodies() if int(b) not in tasked]
+    assert len(hand) == 14
+    assert np.all(q[:, hand] == 0.0)
+
+
+def test_limits_respected_and_gain_rule():
+    """Hard targets push joints to their range: qpos never leaves [lo, hi] and every step obeys dq <= 0.95 (hi - q)."""
+    cm = compiled("smplx", "unitree_g1")
+    orc = Oracle(cm.blob)
+    pos, quat, names, offs, _ = synth.synth_clips(cm, 1, 40, seed=4, hard=True, dtype=np.float64)
+    sc = cm.slot_columns(names)
+    q, _, _ = orc.ik_solve(pos, quat, sc, make_items(offs, WORK_ITEM_DTYPE))
+    lo, hi = cm.robot.dof_limits()
+    assert np.all(q[:, 7:] >= lo - 1e-12) and np.all(q[:, 7:] <= hi + 1e-12)
+    tp, tq = orc.prepare_targets(pos[5][sc], quat[5][sc])
+    H, c, blo, bhi = orc.build_qp(0, q[4], tp, tq)
+    np.testing.assert_allclose(bhi[6:], 0.95 * (hi - q[4, 7:]), atol=1e-15)
+    np.testing.assert_allclose(blo[6:], -0.95 * (q[4, 7:] - lo), atol=1e-15)
+    x, _ = box_qp(H, c, blo, bhi)
+    assert _kkt(H, c, blo, bhi, x) < 1e-8 * (1 + np.abs(c).max())
+    assert np.allclose(H, H.T) and np.linalg.eigvalsh(H).min() >= 0.5 - 1e-9
+
+
+def test_work_item_semantics_chunk_equals_sequential_prefix():
+    """A work item with burn-in reproduces the sequential run when it starts at frame 0; init_row/final_row chain state."""
+    cm = compiled("smplx", "unitree_g1")
+    orc = Oracle(cm.blob)
+    pos, quat, names, offs, _ = synth.synth_clips(cm, 1, 30, seed=9, dtype=np.float64)
+    sc = cm.slot_columns(names)
+    q_seq, _, _ = orc.ik_solve(pos, quat, sc, make_items(offs, WORK_ITEM_DTYPE))
+    it = np.zeros(1, WORK_ITEM_DTYPE)
+    it["frame_begin"], it["n_burn"], it["n_out"], it["init_row"], it["final_row"] = 0, 10, 20, -1, 0
+    q_b, _, qf = orc.ik_solve(pos, quat, sc, it, want_final=True)
+    assert np.all(np.isnan(q_b[:10])) and np.array_equal(q_b[10:], q_seq[10:])
+    np.testing.assert_array_equal(qf[0], q_seq[-1])
+    it2 = np.zeros(1, WORK_ITEM_DTYPE)
+    it2["frame_begin"], it2["n_burn"], it2["n_out"], it2["init_row"], it2["final_row"] = 15, 0, 15, 0, -1
+    q_c, _, _ = orc.ik_solve(pos, quat, sc, it2, qpos_init=q_seq[14:15])
+    np.testing.assert_array_equal(q_c[15:], q_seq[15:])
+
+
+def test_offset_to_ground_and_height_ratio():
+    cm = compiled("bvh", "unitree_g1", 1.6)
+    assert abs(cm.ratio - 1.6 / cm.config.human_height_assumption) < 1e-15
+    orc = Oracle(cm.blob)
+    rng = np.random.default_rng(0)
+    hp = rng.normal(size=(cm.nslot, 3))
+    hq = rng.normal(size=(cm.nslot, 4))
+    tp, tq = orc.prepare_targets(hp, hq, offset_to_ground=True)
+    feet = [i for i, n in enumerate(cm.slot_names) if "Foot" in n or "foot" in n]
+    assert len(feet) == 2 and abs(tp[feet, 2].min() - 0.1) < 1e-12
+    tp0, _ = orc.prepare_targets(hp, hq)
+    rs = cm.root_slot
+    assert np.allclose(tp0[rs] - synth.qrot(tq[rs], cm.slot_pos_off[rs]), cm.slot_scale[rs] * hp[rs])
