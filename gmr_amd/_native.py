@@ -1,0 +1,89 @@
+"""ctypes binding of libgmr_amd.so (the C ABI in include/gmr_amd.h).
+
+Fails loudly: if the shared library is missing or does not export the expected ABI,
+importing anything that needs it raises -- there is no Python/CPU fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import LIB_PATH
+
+ABI_VERSION = 1
+GMR_DTYPE_F32, GMR_DTYPE_F64 = 0, 1
+
+WORK_ITEM_DTYPE = np.dtype(
+    [("frame_begin", "<i8"), ("n_burn", "<i4"), ("n_out", "<i4"), ("init_row", "<i4"), ("final_row", "<i4")], align=True
+)
+assert WORK_ITEM_DTYPE.itemsize == 24
+
+EXPORTS = ["gmr_abi_version", "gmr_model_create", "gmr_model_destroy", "gmr_last_error", "gmr_model_info_get",
+           "gmr_ik_solve", "gmr_fk", "gmr_fk_min_height"]
+
+
+class IKParams(C.Structure):
+    """``gmr_ik_params`` (include/gmr_blob.h); defaults = the reference's constants."""
+
+    _fields_ = [
+        ("damping", C.c_double), ("tol", C.c_double), ("limit_gain", C.c_double), ("lm_damping", C.c_double),
+        ("max_iter", C.c_int32), ("offset_to_ground", C.c_int32), ("reserved", C.c_int32 * 2),
+    ]
+
+    def __init__(self, damping=0.5, tol=1e-3, limit_gain=0.95, lm_damping=1.0, max_iter=10, offset_to_ground=0):
+        super().__init__(float(damping), float(tol), float(limit_gain), float(lm_damping), int(max_iter), int(offset_to_ground))
+
+
+class ModelInfo(C.Structure):
+    _fields_ = [
+        ("nbody", C.c_int32), ("nq", C.c_int32), ("nv", C.c_int32), ("nslot", C.c_int32), ("ntask", C.c_int32 * 2),
+        ("n_active_dof", C.c_int32), ("nv_padded", C.c_int32), ("lds_bytes", C.c_int32), ("device", C.c_int32),
+        ("reserved", C.c_int32 * 6),
+    ]
+
+
+class IKStats(C.Structure):
+    _fields_ = [("n_items", C.c_int64), ("n_frames_total", C.c_int64), ("n_frames_out", C.c_int64), ("reserved", C.c_int32 * 4)]
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Return the loaded library, raising ``NativeLibraryError`` if it is unusable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -m gmr_amd.build` (hipcc, gfx950). "
+            "gmr_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    missing = [s for s in EXPORTS if not hasattr(L, s)]
+    if missing:
+        raise NativeLibraryError(f"{LIB_PATH} does not export {missing}")
+    vp = C.c_void_p
+    L.gmr_abi_version.restype = C.c_int
+    if L.gmr_abi_version() != ABI_VERSION:
+        raise NativeLibraryError(f"ABI version mismatch: library {L.gmr_abi_version()}, binding {ABI_VERSION}")
+    L.gmr_model_create.restype = vp
+    L.gmr_model_create.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t]
+    L.gmr_model_destroy.argtypes = [vp]
+    L.gmr_last_error.restype = C.c_char_p
+    L.gmr_last_error.argtypes = [vp]
+    L.gmr_model_info_get.argtypes = [vp, C.POINTER(ModelInfo)]
+    L.gmr_ik_solve.restype = C.c_int
+    L.gmr_ik_solve.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int64, vp, C.c_int, C.POINTER(IKParams), vp, vp, vp, vp,
+                               C.POINTER(IKStats), vp]
+    L.gmr_fk.restype = C.c_int
+    L.gmr_fk.argtypes = [vp, vp, vp, vp, C.c_int64, vp, vp, vp]
+    L.gmr_fk_min_height.restype = C.c_int
+    L.gmr_fk_min_height.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp]
+    _lib = L
+    return L

@@ -1,0 +1,50 @@
+"""Build libgmr_amd.so (HIP, gfx950) in-tree with hipcc.
+
+    python -m gmr_amd.build [--force]
+
+hipcc cross-compiles without a GPU; the resulting ``gmr_amd/lib/libgmr_amd.so`` is
+git-ignored but travels to the GPU box with the working tree.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libgmr_amd.so")
+SOURCES = ["api.hip"]
+DEPS = ["api.hip", "ik_kernel.hip.h", "fk_kernel.hip.h"]
+HEADERS = ["gmr_amd.h", "gmr_blob.h"]
+ARCH = "gfx950"
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in DEPS] + [os.path.join(INCLUDE, f) for f in HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libgmr_amd.so (no CPU fallback exists)")
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{INCLUDE}", "-Wno-unused-value",
+           "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv, verbose=True))

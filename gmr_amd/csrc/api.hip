@@ -1,0 +1,460 @@
+// api.hip -- C ABI of libgmr_amd.so (include/gmr_amd.h): model handle, scheduling, kernel launches.
+//
+// Host side is plain C++: blob validation, the derived index structures the kernels want (tree depth
+// levels, active-dof list, ancestor masks, composite nodes of the task tree, FK branch-slot plan), one
+// device allocation per model, a grow-only scheduling workspace, and shape checks in front of every
+// launch.  No torch, no CPU fallback: every failure is reported, nothing is silently computed elsewhere.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "fk_kernel.hip.h"
+#include "ik_kernel.hip.h"
+
+using gmr::u64;
+
+struct gmr_model {
+  int device = -1;
+  gmr_blob_header h{};
+  std::vector<uint8_t> blob;
+  std::string err;
+  // device storage
+  void *dev = nullptr;
+  size_t dev_bytes = 0;
+  gmr::DevModel dm{};
+  gmr::FkTree fk{};
+  gmr::LdsLayout lay{};
+  int nvp = 0, n_act = 0, lds_bytes = 0, fk_lds_bytes = 0;
+  // grow-only workspace for per-call scheduling data
+  void *ws = nullptr;
+  size_t ws_bytes = 0;
+};
+
+namespace {
+
+void set_err(gmr_model *m, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (m) m->err = buf;
+}
+
+#define HIP_TRY(m, expr)                                                              \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess) {                                                           \
+      set_err(m, "%s failed: %s", #expr, hipGetErrorString(e_));                      \
+      return GMR_EDEVICE;                                                             \
+    }                                                                                 \
+  } while (0)
+
+template <class T>
+const T *blob_ptr(const std::vector<uint8_t> &b, uint32_t off) {
+  return reinterpret_cast<const T *>(b.data() + off);
+}
+
+bool range_ok(const gmr_blob_header &h, uint32_t off, size_t bytes) {
+  return off >= sizeof(gmr_blob_header) && (off & 7u) == 0 && (size_t)off + bytes <= h.total_bytes;
+}
+
+// Packs host arrays into one device image, remembering where each one went.
+struct Packer {
+  std::vector<uint8_t> buf;
+  template <class T>
+  size_t add(const std::vector<T> &v) {
+    size_t off = (buf.size() + 15) & ~size_t(15);
+    buf.resize(off + std::max<size_t>(v.size(), 1) * sizeof(T));
+    if (!v.empty()) memcpy(buf.data() + off, v.data(), v.size() * sizeof(T));
+    return off;
+  }
+};
+
+int ensure_ws(gmr_model *m, size_t bytes) {
+  if (bytes <= m->ws_bytes) return GMR_OK;
+  if (m->ws) HIP_TRY(m, hipFree(m->ws));
+  m->ws = nullptr;
+  m->ws_bytes = 0;
+  size_t cap = std::max<size_t>(bytes * 2, 1 << 16);
+  HIP_TRY(m, hipMalloc(&m->ws, cap));
+  m->ws_bytes = cap;
+  return GMR_OK;
+}
+
+int pick_nvp(int n_act) {
+  const int variants[] = {32, 36, 40, 48, 64};
+  for (int v : variants)
+    if (n_act <= v) return v;
+  return -1;
+}
+
+template <int NVP>
+void launch_ik(const gmr_model *m, const gmr::IkLaunch &L, hipStream_t st) {
+  hipLaunchKernelGGL((gmr::ik_kernel<NVP>), dim3(L.n_items), dim3(64), m->lds_bytes, st, m->dm, L, m->lay);
+}
+
+int build_device_model(gmr_model *m) {
+  const gmr_blob_header &h = m->h;
+  const auto &B = m->blob;
+  const int nb = h.nbody;
+  const int32_t *parent = blob_ptr<int32_t>(B, h.off_parent), *jtype = blob_ptr<int32_t>(B, h.off_jnt_type);
+  const int32_t *qadr = blob_ptr<int32_t>(B, h.off_qpos_adr), *dadr = blob_ptr<int32_t>(B, h.off_dof_adr);
+  const int32_t *limited = blob_ptr<int32_t>(B, h.off_jnt_limited);
+  const double *bpos = blob_ptr<double>(B, h.off_body_pos), *bquat = blob_ptr<double>(B, h.off_body_quat);
+  const double *bquat_raw = blob_ptr<double>(B, h.off_body_quat_raw), *axis = blob_ptr<double>(B, h.off_jnt_axis);
+  const double *range = blob_ptr<double>(B, h.off_jnt_range), *qpos0 = blob_ptr<double>(B, h.off_qpos0);
+
+  // ---- tree sanity: depth-first order, free root, hinges elsewhere ----
+  if (parent[0] != -1 || jtype[0] != GMR_JNT_FREE || qadr[0] != 0 || dadr[0] != 0) {
+    set_err(m, "body 0 must be the free-joint root");
+    return GMR_EINVAL;
+  }
+  std::vector<int> depth(nb, 0);
+  int maxdepth = 0, nq = 7, nv = 6;
+  for (int b = 1; b < nb; ++b) {
+    if (parent[b] < 0 || parent[b] >= b) { set_err(m, "bodies are not in depth-first order"); return GMR_EINVAL; }
+    depth[b] = depth[parent[b]] + 1;
+    maxdepth = std::max(maxdepth, depth[b]);
+    if (jtype[b] == GMR_JNT_HINGE) {
+      if (qadr[b] != nq || dadr[b] != nv) { set_err(m, "joint addresses out of order at body %d", b); return GMR_EINVAL; }
+      ++nq; ++nv;
+    } else if (jtype[b] != GMR_JNT_NONE) { set_err(m, "unsupported joint type at body %d", b); return GMR_EUNSUPPORTED; }
+  }
+  if (nq != h.nq || nv != h.nv) { set_err(m, "nq/nv do not match the joint list"); return GMR_EINVAL; }
+
+  // ---- tasks ----
+  std::vector<int> tbody(2 * GMR_MAX_TASKS, 0), tslot(2 * GMR_MAX_TASKS, 0);
+  std::vector<double> twp(2 * GMR_MAX_TASKS, 0.0), twr(2 * GMR_MAX_TASKS, 0.0);
+  for (int k = 0; k < 2; ++k) {
+    const int32_t *tb = blob_ptr<int32_t>(B, h.off_task_body[k]), *ts = blob_ptr<int32_t>(B, h.off_task_slot[k]);
+    const double *wp = blob_ptr<double>(B, h.off_task_wp[k]), *wr = blob_ptr<double>(B, h.off_task_wr[k]);
+    for (int t = 0; t < h.ntask[k]; ++t) {
+      if (tb[t] < 0 || tb[t] >= nb || ts[t] < 0 || ts[t] >= h.nslot) { set_err(m, "task %d of table %d out of range", t, k + 1); return GMR_EINVAL; }
+      tbody[k * GMR_MAX_TASKS + t] = tb[t]; tslot[k * GMR_MAX_TASKS + t] = ts[t];
+      twp[k * GMR_MAX_TASKS + t] = wp[t]; twr[k * GMR_MAX_TASKS + t] = wr[t];
+    }
+  }
+  // body a is an ancestor-or-self of body b ?
+  auto above = [&](int a, int b) {
+    while (b > a) b = parent[b];
+    return b == a;
+  };
+  // ---- active dofs: root 6 + hinges with at least one task (either table) at or below them ----
+  std::vector<int> abody, akind, aqadr, alim;
+  std::vector<double> arange;
+  for (int k = 0; k < 6; ++k) { abody.push_back(0); akind.push_back(k); aqadr.push_back(k < 3 ? k : 3); alim.push_back(0); arange.push_back(0); arange.push_back(0); }
+  for (int b = 1; b < nb; ++b) {
+    if (jtype[b] != GMR_JNT_HINGE) continue;
+    bool used = false;
+    for (int k = 0; k < 2 && !used; ++k)
+      for (int t = 0; t < h.ntask[k] && !used; ++t) used = above(b, tbody[k * GMR_MAX_TASKS + t]);
+    if (!used) continue;
+    abody.push_back(b); akind.push_back(6); aqadr.push_back(qadr[b]); alim.push_back(limited[b] ? 1 : 0);
+    arange.push_back(range[2 * b]); arange.push_back(range[2 * b + 1]);
+  }
+  const int n_act = (int)abody.size();
+  const int nvp = pick_nvp(n_act);
+  if (nvp < 0) { set_err(m, "%d active dofs exceed the kernel limit of 64", n_act); return GMR_EUNSUPPORTED; }
+  std::vector<u64> aanc(64, 0);
+  for (int i = 0; i < n_act; ++i) {
+    u64 mk = 0;
+    for (int j = 0; j < i; ++j) {
+      bool anc;
+      if (akind[i] < 6) anc = true;                 // root dofs form a chain 0 <- 1 <- ... <- 5
+      else if (akind[j] < 6) anc = true;            // every hinge hangs below the root's six dofs
+      else anc = abody[j] != abody[i] && above(abody[j], abody[i]);
+      if (anc) mk |= 1ull << j;
+    }
+    aanc[i] = mk;
+  }
+  // ---- composites per table: dofs sharing the same set of tasks below them share one 6x6 block ----
+  std::vector<int> acomp(2 * 64, 0);
+  std::vector<unsigned> compmask(2 * 2 * GMR_MAX_TASKS, 0u);
+  int ncomp[2] = {0, 0};
+  for (int k = 0; k < 2; ++k) {
+    std::map<unsigned, int> ids;
+    for (int i = 0; i < n_act; ++i) {
+      unsigned mk = 0;
+      for (int t = 0; t < h.ntask[k]; ++t)
+        if (akind[i] < 6 || above(abody[i], tbody[k * GMR_MAX_TASKS + t])) mk |= 1u << t;
+      auto it = ids.find(mk);
+      if (it == ids.end()) {
+        it = ids.emplace(mk, ncomp[k]).first;
+        compmask[k * 2 * GMR_MAX_TASKS + ncomp[k]] = mk;
+        ++ncomp[k];
+      }
+      acomp[k * 64 + i] = it->second;
+    }
+    if (ncomp[k] > 2 * GMR_MAX_TASKS) { set_err(m, "too many composite nodes"); return GMR_EUNSUPPORTED; }
+  }
+  // ---- FK (KinematicsModel convention) tables and branch-slot plan ----
+  std::vector<int> dofidx(nb, -1), src_slot(nb, -1), save_slot(nb, -1), last_child(nb, -1), nchild_other(nb, 0);
+  std::vector<float> lpos(3 * nb), lrot(4 * nb), jaxis(3 * nb);
+  std::vector<double> jaxis64(3 * nb);
+  for (int b = 0; b < nb; ++b) {
+    if (jtype[b] == GMR_JNT_HINGE) dofidx[b] = qadr[b] - 7;
+    for (int i = 0; i < 3; ++i) { lpos[3 * b + i] = (float)bpos[3 * b + i]; jaxis[3 * b + i] = (float)axis[3 * b + i]; jaxis64[3 * b + i] = axis[3 * b + i]; }
+    lrot[4 * b + 0] = (float)bquat_raw[4 * b + 1]; lrot[4 * b + 1] = (float)bquat_raw[4 * b + 2];
+    lrot[4 * b + 2] = (float)bquat_raw[4 * b + 3]; lrot[4 * b + 3] = (float)bquat_raw[4 * b + 0];
+    if (b > 0) { last_child[parent[b]] = b; if (parent[b] != b - 1) nchild_other[parent[b]]++; }
+  }
+  std::vector<int> free_slots;
+  int nslots = 0;
+  for (int b = 0; b < nb; ++b) {
+    if (b > 0 && parent[b] != b - 1) {
+      src_slot[b] = save_slot[parent[b]];
+      if (src_slot[b] < 0) { set_err(m, "internal: FK slot plan"); return GMR_EINVAL; }
+    }
+    if (b > 0 && last_child[parent[b]] == b && save_slot[parent[b]] >= 0) free_slots.push_back(save_slot[parent[b]]);
+    if (nchild_other[b] > 0) {
+      if (!free_slots.empty()) { save_slot[b] = free_slots.back(); free_slots.pop_back(); }
+      else save_slot[b] = nslots++;
+    }
+  }
+  if (nslots > gmr::kFkMaxSlots) { set_err(m, "tree too bushy for the FK kernel (%d branch slots)", nslots); return GMR_EUNSUPPORTED; }
+
+  // ---- pack + upload ----
+  std::vector<int> v_parent(parent, parent + nb), v_jtype(jtype, jtype + nb), v_qadr(qadr, qadr + nb);
+  std::vector<double> v_bpos(bpos, bpos + 3 * nb), v_bquat(bquat, bquat + 4 * nb), v_axis(axis, axis + 3 * nb), v_qpos0(qpos0, qpos0 + nq);
+  const int ns = h.nslot;
+  std::vector<double> v_sscale(blob_ptr<double>(B, h.off_slot_scale), blob_ptr<double>(B, h.off_slot_scale) + ns);
+  std::vector<double> v_spoff(blob_ptr<double>(B, h.off_slot_pos_off), blob_ptr<double>(B, h.off_slot_pos_off) + 3 * ns);
+  std::vector<double> v_sroff(blob_ptr<double>(B, h.off_slot_rot_off), blob_ptr<double>(B, h.off_slot_rot_off) + 4 * ns);
+  std::vector<int> v_sfoot(blob_ptr<int32_t>(B, h.off_slot_is_foot), blob_ptr<int32_t>(B, h.off_slot_is_foot) + ns);
+  abody.resize(64, 0); akind.resize(64, 0); aqadr.resize(64, 0); alim.resize(64, 0); arange.resize(128, 0.0);
+
+  Packer P;
+  const size_t o_parent = P.add(v_parent), o_jtype = P.add(v_jtype), o_qadr = P.add(v_qadr), o_depth = P.add(depth);
+  const size_t o_bpos = P.add(v_bpos), o_bquat = P.add(v_bquat), o_axis = P.add(v_axis), o_qpos0 = P.add(v_qpos0);
+  const size_t o_sscale = P.add(v_sscale), o_spoff = P.add(v_spoff), o_sroff = P.add(v_sroff), o_sfoot = P.add(v_sfoot);
+  const size_t o_tbody = P.add(tbody), o_tslot = P.add(tslot), o_twp = P.add(twp), o_twr = P.add(twr);
+  const size_t o_abody = P.add(abody), o_akind = P.add(akind), o_aqadr = P.add(aqadr), o_alim = P.add(alim);
+  const size_t o_aanc = P.add(aanc), o_arange = P.add(arange), o_acomp = P.add(acomp), o_compmask = P.add(compmask);
+  const size_t o_dofidx = P.add(dofidx), o_src = P.add(src_slot), o_save = P.add(save_slot);
+  const size_t o_lpos = P.add(lpos), o_lrot = P.add(lrot), o_jaxis = P.add(jaxis), o_jaxis64 = P.add(jaxis64);
+
+  HIP_TRY(m, hipMalloc(&m->dev, P.buf.size()));
+  m->dev_bytes = P.buf.size();
+  HIP_TRY(m, hipMemcpy(m->dev, P.buf.data(), P.buf.size(), hipMemcpyHostToDevice));
+  const uint8_t *D = static_cast<const uint8_t *>(m->dev);
+#define DP(T, off) reinterpret_cast<const T *>(D + (off))
+  gmr::DevModel &dm = m->dm;
+  dm.nbody = nb; dm.nq = nq; dm.nv = nv; dm.nslot = ns; dm.root_slot = h.root_slot; dm.maxdepth = maxdepth; dm.n_act = n_act;
+  for (int k = 0; k < 2; ++k) { dm.ntask[k] = h.ntask[k]; dm.use_table[k] = h.use_table[k] && h.ntask[k] > 0; dm.ncomp[k] = ncomp[k]; }
+  dm.parent = DP(int, o_parent); dm.jtype = DP(int, o_jtype); dm.qadr = DP(int, o_qadr); dm.depth = DP(int, o_depth);
+  dm.bpos = DP(double, o_bpos); dm.bquat = DP(double, o_bquat); dm.axis = DP(double, o_axis); dm.qpos0 = DP(double, o_qpos0);
+  dm.sscale = DP(double, o_sscale); dm.spoff = DP(double, o_spoff); dm.sroff = DP(double, o_sroff); dm.sfoot = DP(int, o_sfoot);
+  dm.tbody = DP(int, o_tbody); dm.tslot = DP(int, o_tslot); dm.twp = DP(double, o_twp); dm.twr = DP(double, o_twr);
+  dm.abody = DP(int, o_abody); dm.akind = DP(int, o_akind); dm.aqadr = DP(int, o_aqadr); dm.alimited = DP(int, o_alim);
+  dm.aanc = DP(u64, o_aanc); dm.arange = DP(double, o_arange); dm.acomp = DP(int, o_acomp); dm.compmask = DP(unsigned, o_compmask);
+  gmr::FkTree &fk = m->fk;
+  fk.parent = DP(int, o_parent); fk.dofidx = DP(int, o_dofidx); fk.src_slot = DP(int, o_src); fk.save_slot = DP(int, o_save);
+  fk.lpos = DP(float, o_lpos); fk.lrot = DP(float, o_lrot); fk.jaxis = DP(float, o_jaxis); fk.jaxis64 = DP(double, o_jaxis64);
+  fk.nbody = nb; fk.ndof = nq - 7; fk.nslots = nslots; fk.pad = 0;
+#undef DP
+  m->fk_lds_bytes = std::max(1, nslots) * 7 * gmr::kFkThreads * (int)sizeof(float);
+
+  // ---- LDS layout of the IK kernel (doubles) ----
+  const int ntmax = std::max(h.ntask[0], h.ntask[1]), ncmax = std::max(ncomp[0], ncomp[1]);
+  gmr::LdsLayout &L = m->lay;
+  int o = 0;
+  L.q = o; o += (nq + 1) & ~1;
+  L.tp = o; o += 3 * ns + (ns & 1);
+  L.tq = o; o += 4 * ns;
+  L.S = o; o += 6 * nvp;
+  L.xpos = o; L.H = o;
+  int r = o;
+  r += 3 * nb + (nb & 1);
+  L.xquat = r; r += 4 * nb;
+  L.B = r; r += gmr::kBT * ntmax + ((gmr::kBT * ntmax) & 1);
+  L.Bc = r; r += gmr::kBT * ncmax + ((gmr::kBT * ncmax) & 1);
+  o = std::max(r, o + nvp * nvp);
+  L.total_doubles = o;
+  m->lds_bytes = o * (int)sizeof(double);
+  m->nvp = nvp;
+  m->n_act = n_act;
+  if (m->lds_bytes > 160 * 1024) { set_err(m, "model needs %d bytes of LDS per wavefront", m->lds_bytes); return GMR_EUNSUPPORTED; }
+  // opt in to > 64 KiB of dynamic LDS where a variant needs it
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<36>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<40>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<48>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipGetLastError();
+  return GMR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gmr_abi_version(void) { return GMR_ABI_VERSION; }
+
+gmr_model *gmr_model_create(const void *blob, size_t blob_bytes, int device, char *err, size_t err_len) {
+  auto fail = [&](gmr_model *m, const char *msg) -> gmr_model * {
+    if (err && err_len) snprintf(err, err_len, "%s", m && !m->err.empty() ? m->err.c_str() : msg);
+    if (m) gmr_model_destroy(m);
+    return nullptr;
+  };
+  if (!blob || blob_bytes < sizeof(gmr_blob_header)) return fail(nullptr, "blob too small");
+  gmr_blob_header h;
+  memcpy(&h, blob, sizeof(h));
+  if (h.magic != GMR_BLOB_MAGIC || h.version != GMR_BLOB_VERSION) return fail(nullptr, "bad blob magic/version");
+  if (h.total_bytes != blob_bytes) return fail(nullptr, "blob size mismatch");
+  if (h.nbody < 1 || h.nbody > GMR_MAX_BODIES) return fail(nullptr, "nbody outside [1, 64]");
+  if (h.nq != h.nv + 1 || h.nv < 6) return fail(nullptr, "bad nq/nv");
+  if (h.nslot < 0 || h.nslot > GMR_MAX_SLOTS || h.ntask[0] < 0 || h.ntask[0] > GMR_MAX_TASKS || h.ntask[1] < 0 || h.ntask[1] > GMR_MAX_TASKS)
+    return fail(nullptr, "slot/task counts out of range");
+  if (h.nslot > 0 && (h.root_slot < 0 || h.root_slot >= h.nslot)) return fail(nullptr, "root_slot out of range");
+  const size_t nb = h.nbody, ns = h.nslot;
+  bool ok = range_ok(h, h.off_parent, nb * 4) && range_ok(h, h.off_jnt_type, nb * 4) && range_ok(h, h.off_qpos_adr, nb * 4) &&
+            range_ok(h, h.off_dof_adr, nb * 4) && range_ok(h, h.off_jnt_limited, nb * 4) && range_ok(h, h.off_body_pos, nb * 24) &&
+            range_ok(h, h.off_body_quat, nb * 32) && range_ok(h, h.off_body_quat_raw, nb * 32) && range_ok(h, h.off_jnt_axis, nb * 24) &&
+            range_ok(h, h.off_jnt_range, nb * 16) && range_ok(h, h.off_qpos0, (size_t)h.nq * 8) && range_ok(h, h.off_slot_scale, ns * 8) &&
+            range_ok(h, h.off_slot_pos_off, ns * 24) && range_ok(h, h.off_slot_rot_off, ns * 32) && range_ok(h, h.off_slot_is_foot, ns * 4);
+  for (int k = 0; k < 2; ++k)
+    ok = ok && range_ok(h, h.off_task_body[k], (size_t)h.ntask[k] * 4) && range_ok(h, h.off_task_slot[k], (size_t)h.ntask[k] * 4) &&
+         range_ok(h, h.off_task_wp[k], (size_t)h.ntask[k] * 8) && range_ok(h, h.off_task_wr[k], (size_t)h.ntask[k] * 8);
+  if (!ok) return fail(nullptr, "blob array offsets out of range");
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, "no HIP device available (libgmr_amd has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(nullptr, "device ordinal out of range");
+  gmr_model *m = new gmr_model();
+  m->device = device;
+  m->h = h;
+  m->blob.assign(static_cast<const uint8_t *>(blob), static_cast<const uint8_t *>(blob) + blob_bytes);
+  if (hipSetDevice(device) != hipSuccess) return fail(m, "hipSetDevice failed");
+  if (build_device_model(m) != GMR_OK) return fail(m, "model build failed");
+  return m;
+}
+
+void gmr_model_destroy(gmr_model *m) {
+  if (!m) return;
+  if (m->device >= 0) (void)hipSetDevice(m->device);
+  if (m->dev) (void)hipFree(m->dev);
+  if (m->ws) (void)hipFree(m->ws);
+  delete m;
+}
+
+const char *gmr_last_error(const gmr_model *m) { return m ? m->err.c_str() : "null model"; }
+
+int gmr_model_info_get(const gmr_model *m, gmr_model_info *out) {
+  if (!m || !out) return GMR_EINVAL;
+  memset(out, 0, sizeof(*out));
+  out->nbody = m->h.nbody; out->nq = m->h.nq; out->nv = m->h.nv; out->nslot = m->h.nslot;
+  out->ntask[0] = m->h.ntask[0]; out->ntask[1] = m->h.ntask[1];
+  out->n_active_dof = m->n_act; out->nv_padded = m->nvp; out->lds_bytes = m->lds_bytes; out->device = m->device;
+  return GMR_OK;
+}
+
+int gmr_ik_solve(gmr_model *m, const void *human_pos, const void *human_quat, int in_dtype, int n_cols, const int32_t *slot_col,
+                 int64_t n_frames, const gmr_work_item *items, int n_items, const gmr_ik_params *params, const double *qpos_init,
+                 double *qpos_final, double *qpos_out, int32_t *iters_out, gmr_ik_stats *stats, void *stream) {
+  if (!m) return GMR_EINVAL;
+  m->err.clear();
+  if (m->h.nslot == 0 || (m->h.ntask[0] == 0 && m->h.ntask[1] == 0)) { set_err(m, "model has no IK config"); return GMR_ENOCONFIG; }
+  if (!human_pos || !human_quat || !slot_col || !params || !qpos_out || (!items && n_items > 0)) { set_err(m, "null argument"); return GMR_EINVAL; }
+  if (in_dtype != GMR_DTYPE_F32 && in_dtype != GMR_DTYPE_F64) { set_err(m, "in_dtype must be f32 or f64"); return GMR_EINVAL; }
+  if (n_cols <= 0 || n_frames < 0 || n_items < 0) { set_err(m, "negative size"); return GMR_EINVAL; }
+  if (params->max_iter < 0 || !(params->damping > 0.0)) { set_err(m, "damping must be > 0 (H must be positive definite) and max_iter >= 0"); return GMR_EINVAL; }
+  for (int s = 0; s < m->h.nslot; ++s)
+    if (slot_col[s] < 0 || slot_col[s] >= n_cols) { set_err(m, "slot_col[%d]=%d outside [0,%d)", s, slot_col[s], n_cols); return GMR_EINVAL; }
+  int64_t tot = 0, out = 0;
+  bool need_init = false, need_final = false;
+  for (int i = 0; i < n_items; ++i) {
+    const gmr_work_item &w = items[i];
+    if (w.n_burn < 0 || w.n_out < 0 || w.frame_begin < 0 || w.frame_begin + w.n_burn + w.n_out > n_frames) {
+      set_err(m, "work item %d covers frames outside [0,%lld)", i, (long long)n_frames);
+      return GMR_EINVAL;
+    }
+    tot += w.n_burn + w.n_out; out += w.n_out;
+    need_init |= w.init_row >= 0; need_final |= w.final_row >= 0;
+  }
+  if (need_init && !qpos_init) { set_err(m, "items reference qpos_init but it is NULL"); return GMR_EINVAL; }
+  if (need_final && !qpos_final) { set_err(m, "items reference qpos_final but it is NULL"); return GMR_EINVAL; }
+  if (stats) { memset(stats, 0, sizeof(*stats)); stats->n_items = n_items; stats->n_frames_total = tot; stats->n_frames_out = out; }
+  if (n_items == 0) return GMR_OK;
+
+  HIP_TRY(m, hipSetDevice(m->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // longest item first so that the tail of the grid is made of short ones
+  std::vector<gmr_work_item> sorted(items, items + n_items);
+  std::stable_sort(sorted.begin(), sorted.end(), [](const gmr_work_item &a, const gmr_work_item &b) { return a.n_burn + a.n_out > b.n_burn + b.n_out; });
+  const size_t items_bytes = sizeof(gmr_work_item) * (size_t)n_items, col_bytes = sizeof(int32_t) * (size_t)m->h.nslot;
+  const size_t col_off = (items_bytes + 15) & ~size_t(15);
+  int rc = ensure_ws(m, col_off + col_bytes);
+  if (rc != GMR_OK) return rc;
+  // pageable-host copies are staged by the runtime before returning, so the vectors may die after the call
+  HIP_TRY(m, hipMemcpyAsync(m->ws, sorted.data(), items_bytes, hipMemcpyHostToDevice, st));
+  HIP_TRY(m, hipMemcpyAsync(static_cast<uint8_t *>(m->ws) + col_off, slot_col, col_bytes, hipMemcpyHostToDevice, st));
+
+  gmr::IkLaunch L{};
+  L.hpos = human_pos; L.hquat = human_quat; L.slot_col = reinterpret_cast<const int *>(static_cast<uint8_t *>(m->ws) + col_off);
+  L.items = static_cast<const gmr_work_item *>(m->ws);
+  L.qinit = qpos_init; L.qfinal = qpos_final; L.qout = qpos_out; L.iters = iters_out;
+  L.in_f64 = in_dtype == GMR_DTYPE_F64; L.n_cols = n_cols; L.n_items = n_items; L.prm = *params;
+  switch (m->nvp) {
+    case 32: launch_ik<32>(m, L, st); break;
+    case 36: launch_ik<36>(m, L, st); break;
+    case 40: launch_ik<40>(m, L, st); break;
+    case 48: launch_ik<48>(m, L, st); break;
+    case 64: launch_ik<64>(m, L, st); break;
+    default: set_err(m, "internal: no kernel variant for nvp=%d", m->nvp); return GMR_EUNSUPPORTED;
+  }
+  HIP_TRY(m, hipGetLastError());
+  return GMR_OK;
+}
+
+int gmr_fk(gmr_model *m, const float *root_pos, const float *root_rot_xyzw, const float *dof, int64_t n_frames, float *body_pos_out,
+           float *body_rot_out, void *stream) {
+  if (!m) return GMR_EINVAL;
+  m->err.clear();
+  if (!root_pos || !root_rot_xyzw || !body_pos_out || (!dof && m->h.nq > 7) || n_frames < 0) { set_err(m, "null argument / negative size"); return GMR_EINVAL; }
+  if (n_frames == 0) return GMR_OK;
+  HIP_TRY(m, hipSetDevice(m->device));
+  const int64_t nblk = (n_frames + gmr::kFkThreads - 1) / gmr::kFkThreads;
+  if (nblk > 0x7fffffff) { set_err(m, "too many frames for one launch"); return GMR_EINVAL; }
+  hipLaunchKernelGGL((gmr::fk_kernel<0>), dim3((unsigned)nblk), dim3(gmr::kFkThreads), m->fk_lds_bytes, static_cast<hipStream_t>(stream), m->fk,
+                     root_pos, root_rot_xyzw, dof, n_frames, body_pos_out, body_rot_out, (const int64_t *)nullptr, 0, (int *)nullptr);
+  HIP_TRY(m, hipGetLastError());
+  return GMR_OK;
+}
+
+int gmr_fk_min_height(gmr_model *m, const float *root_pos, const float *root_rot_xyzw, const float *dof, const int64_t *seq_offsets,
+                      int n_seq, float *min_z_out, void *stream) {
+  if (!m) return GMR_EINVAL;
+  m->err.clear();
+  if (!root_pos || !root_rot_xyzw || !seq_offsets || !min_z_out || n_seq < 0 || (!dof && m->h.nq > 7)) { set_err(m, "null argument / negative size"); return GMR_EINVAL; }
+  if (n_seq == 0) return GMR_OK;
+  for (int s = 0; s < n_seq; ++s)
+    if (seq_offsets[s + 1] < seq_offsets[s] || seq_offsets[0] != 0) { set_err(m, "seq_offsets must start at 0 and be non-decreasing"); return GMR_EINVAL; }
+  const int64_t n_frames = seq_offsets[n_seq];
+  HIP_TRY(m, hipSetDevice(m->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t off_bytes = sizeof(int64_t) * (size_t)(n_seq + 1), key_off = (off_bytes + 15) & ~size_t(15);
+  int rc = ensure_ws(m, key_off + sizeof(int) * (size_t)n_seq);
+  if (rc != GMR_OK) return rc;
+  int *keys = reinterpret_cast<int *>(static_cast<uint8_t *>(m->ws) + key_off);
+  HIP_TRY(m, hipMemcpyAsync(m->ws, seq_offsets, off_bytes, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(gmr::fk_minkey_init, dim3((n_seq + 255) / 256), dim3(256), 0, st, keys, n_seq);
+  if (n_frames > 0) {
+    const int64_t nblk = (n_frames + gmr::kFkThreads - 1) / gmr::kFkThreads;
+    if (nblk > 0x7fffffff) { set_err(m, "too many frames for one launch"); return GMR_EINVAL; }
+    hipLaunchKernelGGL((gmr::fk_kernel<1>), dim3((unsigned)nblk), dim3(gmr::kFkThreads), m->fk_lds_bytes, st, m->fk, root_pos, root_rot_xyzw, dof,
+                       n_frames, (float *)nullptr, (float *)nullptr, static_cast<const int64_t *>(m->ws), n_seq, keys);
+  }
+  hipLaunchKernelGGL(gmr::fk_minkey_decode, dim3((n_seq + 255) / 256), dim3(256), 0, st, keys, min_z_out, n_seq);
+  HIP_TRY(m, hipGetLastError());
+  return GMR_OK;
+}
+
+}  // extern "C"

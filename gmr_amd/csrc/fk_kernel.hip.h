@@ -1,0 +1,168 @@
+// fk_kernel.hip.h -- batched forward kinematics in the KinematicsModel convention (float32, xyzw).
+//
+// Replaces KinematicsModel.forward_kinematics (reference kinematics_model.py:213-246) with its helpers
+// torch_utils.quat_mul :117-138, quat_rotate :65-75, axis_angle_to_quat :353-359, as called by the
+// dataset scripts after IK (scripts/smplx_to_robot_dataset.py:106-123, bvh_to_robot_dataset.py:108-125).
+//
+// One frame per lane.  The joint tree is wave-uniform, so its constants come in through scalar loads
+// (SGPRs) and a copy staged in LDS once per workgroup; the chain itself runs in VGPRs.  Bodies are in
+// depth-first order, so a body's parent is either the previous body (pose still in registers) or an
+// earlier branch point whose pose was parked in a per-lane LDS slot (slot lifetimes planned on the host).
+// Algorithmic HBM traffic per frame: (3+4+ndof) x 4 B in, nbody x 12 B out (+ nbody x 16 B if rotations
+// are requested).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gmr {
+
+constexpr int kFkThreads = 256;
+constexpr int kFkMaxSlots = 12;
+
+struct FkTree {     // device arrays, [nbody]
+  const int *parent, *dofidx, *src_slot, *save_slot;  // dofidx: -1 if no hinge; src_slot: -1 = previous body
+  const float *lpos;   // [nb][3] local translation
+  const float *lrot;   // [nb][4] local rotation xyzw, raw XML values (not normalised)
+  const float *jaxis;  // [nb][3] hinge axis, unit (double normalised, then rounded)
+  const double *jaxis64;  // [nb][3] unit axis in float64 (torch promotes the hinge quaternion to float64)
+  int nbody, ndof, nslots, pad;
+};
+
+__device__ __forceinline__ void fk_quat_mul(const float a[4], const float b[4], float o[4]) {
+  // torch_utils.quat_mul (xyzw), same operation order
+  const float x1 = a[0], y1 = a[1], z1 = a[2], w1 = a[3], x2 = b[0], y2 = b[1], z2 = b[2], w2 = b[3];
+  const float ww = (z1 + x1) * (x2 + y2), yy = (w1 - y1) * (w2 + z2), zz = (w1 + y1) * (w2 - z2);
+  const float xx = ww + yy + zz, qq = 0.5f * (xx + (z1 - x1) * (x2 - y2));
+  o[3] = qq - ww + (z1 - y1) * (y2 - z2);
+  o[0] = qq - xx + (x1 + w1) * (x2 + w2);
+  o[1] = qq - yy + (w1 - x1) * (y2 + z2);
+  o[2] = qq - zz + (z1 + y1) * (w2 - x2);
+}
+__device__ __forceinline__ void fk_quat_rotate(const float q[4], const float v[3], float o[3]) {
+  // torch_utils.quat_rotate: v (2w^2-1) + 2w (q x v) + 2 q (q.v)
+  const float w = q[3], k = 2.0f * w * w - 1.0f;
+  const float cx = q[1] * v[2] - q[2] * v[1], cy = q[2] * v[0] - q[0] * v[2], cz = q[0] * v[1] - q[1] * v[0];
+  const float d = q[0] * v[0] + q[1] * v[1] + q[2] * v[2];
+  o[0] = v[0] * k + cx * w * 2.0f + q[0] * d * 2.0f;
+  o[1] = v[1] * k + cy * w * 2.0f + q[1] * d * 2.0f;
+  o[2] = v[2] * k + cz * w * 2.0f + q[2] * d * 2.0f;
+}
+
+// MODE 0: write body_pos (and body_rot if non-null).  MODE 1: per-clip min of z (atomics on an ordered-int key).
+template <int MODE>
+__global__ void __launch_bounds__(kFkThreads) fk_kernel(FkTree t, const float *__restrict__ root_pos,
+                                                        const float *__restrict__ root_rot, const float *__restrict__ dof,
+                                                        int64_t n_frames, float *__restrict__ body_pos,
+                                                        float *__restrict__ body_rot, const int64_t *__restrict__ seq_offsets,
+                                                        int n_seq, int *__restrict__ min_key) {
+  extern __shared__ float fk_lds[];  // [nslots][7][kFkThreads]
+  const int tid = threadIdx.x;
+  const int64_t f = (int64_t)blockIdx.x * kFkThreads + tid;
+  const bool live = f < n_frames;
+  const int64_t fc = live ? f : n_frames - 1;  // clamp: dead lanes recompute the last frame, never store
+  float cp[3], cr[4];
+#pragma unroll
+  for (int i = 0; i < 3; i++) cp[i] = root_pos[fc * 3 + i];
+#pragma unroll
+  for (int i = 0; i < 4; i++) cr[i] = root_rot[fc * 4 + i];
+  float zmin = cp[2];
+  if (MODE == 0 && live) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) body_pos[(fc * t.nbody) * 3 + i] = cp[i];
+    if (body_rot) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) body_rot[(fc * t.nbody) * 4 + i] = cr[i];
+    }
+  }
+  if (t.save_slot[0] >= 0) {
+    float *s = fk_lds + (size_t)t.save_slot[0] * 7 * kFkThreads + tid;
+#pragma unroll
+    for (int i = 0; i < 3; i++) s[i * kFkThreads] = cp[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) s[(3 + i) * kFkThreads] = cr[i];
+  }
+  const float *mydof = dof + fc * t.ndof;
+  for (int j = 1; j < t.nbody; ++j) {
+    float pp[3], pr[4];
+    const int src = t.src_slot[j];
+    if (src < 0) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) pp[i] = cp[i];
+#pragma unroll
+      for (int i = 0; i < 4; i++) pr[i] = cr[i];
+    } else {
+      const float *s = fk_lds + (size_t)src * 7 * kFkThreads + tid;
+#pragma unroll
+      for (int i = 0; i < 3; i++) pp[i] = s[i * kFkThreads];
+#pragma unroll
+      for (int i = 0; i < 4; i++) pr[i] = s[(3 + i) * kFkThreads];
+    }
+    float jq[4] = {0.f, 0.f, 0.f, 1.f};
+    const int di = t.dofidx[j];
+    if (di >= 0) {
+      // axis_angle_to_quat: sin/cos in float32, the product with the float64 axis and the renormalisation in float64
+      const float th = mydof[di] / 2.0f;
+      const double s = (double)sinf(th), c = (double)cosf(th);
+      const double qx = t.jaxis64[3 * j] * s, qy = t.jaxis64[3 * j + 1] * s, qz = t.jaxis64[3 * j + 2] * s;
+      double n = sqrt(qx * qx + qy * qy + qz * qz + c * c);
+      n = n < 1e-9 ? 1e-9 : n;
+      jq[0] = (float)(qx / n); jq[1] = (float)(qy / n); jq[2] = (float)(qz / n); jq[3] = (float)(c / n);
+    }
+    const float lt[3] = {t.lpos[3 * j], t.lpos[3 * j + 1], t.lpos[3 * j + 2]};
+    const float lr[4] = {t.lrot[4 * j], t.lrot[4 * j + 1], t.lrot[4 * j + 2], t.lrot[4 * j + 3]};
+    float wt[3], tmp[4];
+    fk_quat_rotate(pr, lt, wt);
+#pragma unroll
+    for (int i = 0; i < 3; i++) cp[i] = pp[i] + wt[i];
+    fk_quat_mul(lr, jq, tmp);
+    fk_quat_mul(pr, tmp, cr);
+    if (MODE == 0) {
+      if (live) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) body_pos[(fc * t.nbody + j) * 3 + i] = cp[i];
+        if (body_rot) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) body_rot[(fc * t.nbody + j) * 4 + i] = cr[i];
+        }
+      }
+    } else {
+      zmin = fminf(zmin, cp[2]);
+    }
+    const int sv = t.save_slot[j];
+    if (sv >= 0) {
+      float *s = fk_lds + (size_t)sv * 7 * kFkThreads + tid;
+#pragma unroll
+      for (int i = 0; i < 3; i++) s[i * kFkThreads] = cp[i];
+#pragma unroll
+      for (int i = 0; i < 4; i++) s[(3 + i) * kFkThreads] = cr[i];
+    }
+  }
+  if (MODE == 1 && live) {
+    // clip of this frame: binary search in seq_offsets (wave-divergent, tiny)
+    int lo = 0, hi = n_seq;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (seq_offsets[mid] <= f) lo = mid; else hi = mid;
+    }
+    // order-preserving int key of a float: flip the magnitude bits of negatives
+    int k = __float_as_int(zmin);
+    k = k >= 0 ? k : (k ^ 0x7fffffff);
+    atomicMin(min_key + lo, k);
+  }
+}
+
+__global__ void fk_minkey_init(int *keys, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) keys[i] = 0x7f800000;  // +inf
+}
+__global__ void fk_minkey_decode(const int *keys, float *out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    int k = keys[i];
+    k = k >= 0 ? k : (k ^ 0x7fffffff);
+    out[i] = __int_as_float(k);
+  }
+}
+
+}  // namespace gmr

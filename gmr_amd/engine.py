@@ -1,0 +1,135 @@
+"""Torch-facing wrapper of one native model handle.
+
+PyTorch is plumbing here: device buffers, the current HIP stream, and (elsewhere)
+``torch.distributed``.  All arithmetic happens in libgmr_amd.so's kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _native
+from ._native import IKParams, IKStats, ModelInfo
+from .model import CompiledModel
+
+_ERR = {-1: "invalid argument", -2: "HIP runtime error", -3: "model not supported by the kernels", -4: "model has no IK config"}
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    def __init__(self, cm: CompiledModel, device: int = 0):
+        if not torch.cuda.is_available():
+            raise EngineError("no HIP device visible to torch: the gmr_amd engine has no CPU path")
+        self._lib = _native.load()
+        self.cm = cm
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        err = C.create_string_buffer(512)
+        self._h = self._lib.gmr_model_create(cm.blob, len(cm.blob), self.device_index, err, len(err))
+        if not self._h:
+            raise EngineError(f"gmr_model_create: {err.value.decode()}")
+        info = ModelInfo()
+        self._lib.gmr_model_info_get(self._h, C.byref(info))
+        self.info = info
+        self.nq, self.nv, self.nbody = info.nq, info.nv, info.nbody
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gmr_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self._lib.gmr_last_error(self._h)
+            raise EngineError(f"{what}: {_ERR.get(rc, rc)}: {msg.decode() if msg else ''}")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------
+    def ik_solve(self, pos: torch.Tensor, quat: torch.Tensor, slot_col: np.ndarray, items: np.ndarray,
+                 params: Optional[IKParams] = None, qpos_init: Optional[torch.Tensor] = None, n_final: int = 0,
+                 want_iters: bool = True, out: Optional[torch.Tensor] = None):
+        """pos [N,B,3], quat [N,B,4] (float32 or float64 CUDA tensors) -> qpos [N,nq] float64.
+
+        Frames not covered by any item's output range are left as NaN.  Returns (qpos, iters or None, qpos_final or None).
+        """
+        if pos.device != self.device or quat.device != self.device:
+            raise EngineError("inputs must live on the engine's device")
+        if pos.dtype != quat.dtype or pos.dtype not in (torch.float32, torch.float64):
+            raise EngineError("pos/quat must both be float32 or both float64")
+        if pos.dim() != 3 or quat.dim() != 3 or pos.shape[2] != 3 or quat.shape[2] != 4 or pos.shape[:2] != quat.shape[:2]:
+            raise EngineError(f"bad input shapes {tuple(pos.shape)} / {tuple(quat.shape)}")
+        pos, quat = pos.contiguous(), quat.contiguous()
+        N, B = int(pos.shape[0]), int(pos.shape[1])
+        items = np.ascontiguousarray(items, dtype=_native.WORK_ITEM_DTYPE)
+        slot_col = np.ascontiguousarray(slot_col, dtype=np.int32)
+        if slot_col.shape != (self.info.nslot,):
+            raise EngineError("slot_col has the wrong length")
+        prm = params or IKParams()
+        if out is None:
+            out = torch.full((N, self.nq), float("nan"), dtype=torch.float64, device=self.device)
+        elif out.shape != (N, self.nq) or out.dtype != torch.float64 or not out.is_contiguous() or out.device != self.device:
+            raise EngineError("out must be a contiguous float64 [N, nq] tensor on the engine's device")
+        iters = torch.zeros(N, dtype=torch.int32, device=self.device) if want_iters else None
+        qfin = torch.zeros((n_final, self.nq), dtype=torch.float64, device=self.device) if n_final > 0 else None
+        if qpos_init is not None:
+            if qpos_init.dtype != torch.float64 or qpos_init.dim() != 2 or qpos_init.shape[1] != self.nq or qpos_init.device != self.device:
+                raise EngineError("qpos_init must be float64 [R, nq] on the engine's device")
+            qpos_init = qpos_init.contiguous()
+            if len(items) and int(items["init_row"].max()) >= qpos_init.shape[0]:
+                raise EngineError("init_row outside qpos_init")
+        if len(items) and int(items["final_row"].max()) >= n_final:
+            raise EngineError("final_row outside qpos_final")
+        stats = IKStats()
+        rc = self._lib.gmr_ik_solve(
+            self._h, _ptr(pos), _ptr(quat), _native.GMR_DTYPE_F64 if pos.dtype == torch.float64 else _native.GMR_DTYPE_F32, B,
+            slot_col.ctypes.data_as(C.c_void_p), N, items.ctypes.data_as(C.c_void_p), len(items), C.byref(prm), _ptr(qpos_init),
+            _ptr(qfin), _ptr(out), _ptr(iters), C.byref(stats), self._stream())
+        self._check(rc, "gmr_ik_solve")
+        self.last_stats = stats
+        return out, iters, qfin
+
+    def fk(self, root_pos: torch.Tensor, root_rot_xyzw: torch.Tensor, dof: torch.Tensor, want_rot: bool = True):
+        for t in (root_pos, root_rot_xyzw, dof):
+            if t.device != self.device or t.dtype != torch.float32:
+                raise EngineError("fk inputs must be float32 tensors on the engine's device")
+        T = int(root_pos.shape[0])
+        if root_pos.shape != (T, 3) or root_rot_xyzw.shape != (T, 4) or dof.shape != (T, self.nq - 7):
+            raise EngineError("bad fk input shapes")
+        root_pos, root_rot_xyzw, dof = root_pos.contiguous(), root_rot_xyzw.contiguous(), dof.contiguous()
+        bp = torch.empty((T, self.nbody, 3), dtype=torch.float32, device=self.device)
+        br = torch.empty((T, self.nbody, 4), dtype=torch.float32, device=self.device) if want_rot else None
+        rc = self._lib.gmr_fk(self._h, _ptr(root_pos), _ptr(root_rot_xyzw), _ptr(dof), T, _ptr(bp), _ptr(br), self._stream())
+        self._check(rc, "gmr_fk")
+        return bp, br
+
+    def fk_min_height(self, root_pos: torch.Tensor, root_rot_xyzw: torch.Tensor, dof: torch.Tensor, seq_offsets) -> torch.Tensor:
+        for t in (root_pos, root_rot_xyzw, dof):
+            if t.device != self.device or t.dtype != torch.float32:
+                raise EngineError("fk inputs must be float32 tensors on the engine's device")
+        offs = np.ascontiguousarray(seq_offsets, dtype=np.int64)
+        T = int(root_pos.shape[0])
+        if offs[-1] != T or root_pos.shape != (T, 3) or root_rot_xyzw.shape != (T, 4) or dof.shape != (T, self.nq - 7):
+            raise EngineError("bad fk_min_height shapes")
+        out = torch.empty(len(offs) - 1, dtype=torch.float32, device=self.device)
+        rc = self._lib.gmr_fk_min_height(self._h, _ptr(root_pos.contiguous()), _ptr(root_rot_xyzw.contiguous()), _ptr(dof.contiguous()),
+                                         offs.ctypes.data_as(C.c_void_p), len(offs) - 1, _ptr(out), self._stream())
+        self._check(rc, "gmr_fk_min_height")
+        return out

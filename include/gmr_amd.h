@@ -1,0 +1,111 @@
+/* gmr_amd.h -- C ABI of libgmr_amd.so, the MI355X (gfx950) retarget engine.
+ *
+ * Plain C: opaque handle, raw pointers, sizes.  No torch / C++ types cross this
+ * boundary.  Every pointer documented "device" is a HIP device pointer on the
+ * GPU the handle was created for (e.g. torch.Tensor.data_ptr()); "host" pointers
+ * are ordinary CPU memory.  The caller owns every buffer; the library owns only
+ * the handle (which keeps a copy of the model and a small scheduling workspace).
+ * A handle may be used from one host thread at a time; different handles are
+ * independent.  All calls return 0 on success and a negative GMR_E* code on
+ * failure, with a message available from gmr_last_error().  There is no CPU
+ * fallback: without a usable HIP device gmr_model_create fails.
+ *
+ * What each entry point replaces in the reference (Zudva/GMR):
+ *   gmr_model_create   GeneralMotionRetargeting.__init__ + setup_retarget_configuration
+ *                      (general_motion_retargeting/motion_retarget.py:13-114): mj.MjModel.from_xml_path,
+ *                      mink.Configuration, the two lists of mink.FrameTask;  and
+ *                      KinematicsModel.__init__ (kinematics_model.py:69-99)
+ *   gmr_ik_solve       the caller loop `for frame in frames: qpos = retargeter.retarget(frame)`
+ *                      (scripts/smplx_to_robot_dataset.py:84-89, scripts/bvh_to_robot_dataset.py:95-104)
+ *                      i.e. GeneralMotionRetargeting.retarget / update_targets / error1 / error2
+ *                      (motion_retarget.py:117-200) and, inside it, mink.solve_ik +
+ *                      Configuration.integrate_inplace (call sites motion_retarget.py:147-150,156-159,
+ *                      166-169,176-179)
+ *   gmr_fk             KinematicsModel.forward_kinematics (kinematics_model.py:213-246)
+ *   gmr_fk_min_height  the clip-global `torch.min(body_pos[..., 2])` of the height adjust
+ *                      (scripts/smplx_to_robot_dataset.py:118-126)
+ */
+#ifndef GMR_AMD_H
+#define GMR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "gmr_blob.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GMR_ABI_VERSION 1
+
+#define GMR_OK 0
+#define GMR_EINVAL (-1)    /* bad argument / blob / shape                     */
+#define GMR_EDEVICE (-2)   /* HIP runtime error (no device, launch failure)   */
+#define GMR_EUNSUPPORTED (-3) /* model outside the kernel's limits            */
+#define GMR_ENOCONFIG (-4) /* IK requested on a model compiled without tasks  */
+
+#define GMR_DTYPE_F32 0
+#define GMR_DTYPE_F64 1
+
+typedef struct gmr_model gmr_model;
+
+typedef struct gmr_model_info {
+  int32_t nbody, nq, nv, nslot;
+  int32_t ntask[2];
+  int32_t n_active_dof; /* dofs with at least one task below them (the QP size)   */
+  int32_t nv_padded;    /* compile-time system size of the kernel variant chosen  */
+  int32_t lds_bytes;    /* dynamic LDS per sequence (one wavefront)               */
+  int32_t device;
+  int32_t reserved[6];
+} gmr_model_info;
+
+/* Per-call statistics written by gmr_ik_solve when stats != NULL (host memory). */
+typedef struct gmr_ik_stats {
+  int64_t n_items;        /* work items launched (one wavefront each)             */
+  int64_t n_frames_total; /* frames processed, burn-in included                   */
+  int64_t n_frames_out;   /* frames written                                       */
+  int32_t reserved[4];
+} gmr_ik_stats;
+
+int gmr_abi_version(void);
+
+/* blob: host pointer to a buffer in the layout of gmr_blob.h.  device: HIP device ordinal.
+ * On failure returns NULL and, if err != NULL, writes a NUL-terminated message. */
+gmr_model *gmr_model_create(const void *blob, size_t blob_bytes, int device, char *err, size_t err_len);
+void gmr_model_destroy(gmr_model *m);
+const char *gmr_last_error(const gmr_model *m);
+int gmr_model_info_get(const gmr_model *m, gmr_model_info *out);
+
+/* Batched two-stage IK over work items.
+ *   human_pos  device, [n_frames][n_cols][3] in_dtype, metres
+ *   human_quat device, [n_frames][n_cols][4] in_dtype, wxyz
+ *   slot_col   host,   [nslot] column (0..n_cols-1) of each slot of the model
+ *   items      host,   [n_items] runs of consecutive frames (gmr_work_item)
+ *   qpos_init  device, [*][nq] f64 or NULL (rows referenced by items[].init_row)
+ *   qpos_final device, [*][nq] f64 or NULL (rows referenced by items[].final_row)
+ *   qpos_out   device, [n_frames][nq] f64; only frames covered by an item's n_out are written
+ *   iters_out  device, [n_frames] int32 or NULL: solve_ik calls spent on the frame
+ *              (bit 30 set if a QP hit its iteration cap -- never expected)
+ *   stream     hipStream_t (as void*), NULL = default stream.  The call is
+ *              asynchronous with respect to the host.                             */
+int gmr_ik_solve(gmr_model *m, const void *human_pos, const void *human_quat, int in_dtype, int n_cols,
+                 const int32_t *slot_col, int64_t n_frames, const gmr_work_item *items, int n_items,
+                 const gmr_ik_params *params, const double *qpos_init, double *qpos_final, double *qpos_out,
+                 int32_t *iters_out, gmr_ik_stats *stats, void *stream);
+
+/* Batched FK in the KinematicsModel convention (float32, xyzw).
+ *   root_pos device [n][3], root_rot_xyzw device [n][4], dof device [n][nq-7]
+ *   body_pos_out device [n][nbody][3]; body_rot_out device [n][nbody][4] or NULL   */
+int gmr_fk(gmr_model *m, const float *root_pos, const float *root_rot_xyzw, const float *dof, int64_t n_frames,
+           float *body_pos_out, float *body_rot_out, void *stream);
+
+/* Lowest body z per clip: min over frames [seq_offsets[s], seq_offsets[s+1]) and bodies of FK z.
+ *   seq_offsets host [n_seq+1]; min_z_out device [n_seq] float32                    */
+int gmr_fk_min_height(gmr_model *m, const float *root_pos, const float *root_rot_xyzw, const float *dof,
+                      const int64_t *seq_offsets, int n_seq, float *min_z_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMR_AMD_H */

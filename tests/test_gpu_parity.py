@@ -1,0 +1,66 @@
+"""GPU parity tests: libgmr_amd.so (through the C ABI / Engine) vs the CPU oracle and the golden vectors.
+
+Tolerances: IK qpos is float64 on both sides but assembled by different formulations (composite blocks
+vs dense Jacobians) and a data-dependent loop, so we allow 1e-6 (rad / m) on identical inputs -- three
+orders below the 1e-3 rad target of BASELINE.json; FK is float32, tol 2e-6 as in test_oracle.
+"""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from gmr_amd import synth  # noqa: E402
+from gmr_amd.schedule import make_items  # noqa: E402
+from oracle.oracle import IKParams as OParams, Oracle  # noqa: E402
+from tests.util import CONFIG_ROBOTS, compiled, quat_angle  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device")
+    return torch.device("cuda", 0)
+
+
+def _engine(cm):
+    from gmr_amd.engine import Engine
+    return Engine(cm, 0)
+
+
+def _qpos_diff(a, b):
+    return max(np.abs(a[:, :3] - b[:, :3]).max(), quat_angle(a[:, 3:7], b[:, 3:7]).max(), np.abs(a[:, 7:] - b[:, 7:]).max())
+
+
+@pytest.mark.parametrize("robot", ["unitree_g1", "unitree_g1_with_hands", "booster_t1", "stanford_toddy", "fourier_n1"])
+def test_fk_golden(robot, golden_dir, dev):
+    cm = compiled("smplx", robot)
+    eng = _engine(cm)
+    g = np.load(os.path.join(golden_dir, f"fk_{robot}.npz"))
+    bp, br = eng.fk(torch.from_numpy(g["root_pos"]).to(dev), torch.from_numpy(g["root_rot"]).to(dev), torch.from_numpy(g["dof_pos"]).to(dev))
+    assert np.abs(bp.cpu().numpy() - g["body_pos"]).max() < 2e-6 * max(1.0, np.abs(g["body_pos"]).max())
+    assert np.abs(br.cpu().numpy() - g["body_rot"]).max() < 2e-6
+    T = g["dof_pos"].shape[0]
+    ident = torch.tensor([[0, 0, 0, 1.0]], device=dev).repeat(T, 1)
+    bp0, none = eng.fk(torch.zeros(T, 3, device=dev), ident, torch.from_numpy(g["dof_pos"]).to(dev), want_rot=False)
+    assert none is None
+    assert np.abs(bp0.cpu().numpy() - g["local_body_pos"]).max() < 2e-6
+
+
+@pytest.mark.parametrize("robot", CONFIG_ROBOTS)
+@pytest.mark.parametrize("hard", [False, True])
+def test_ik_matches_oracle(robot, hard, dev):
+    cm = compiled("smplx", robot)
+    eng, orc = _engine(cm), Oracle(cm.blob)
+    pos, quat, names, offs, _ = synth.synth_clips(cm, 3, 40, seed=21, hard=hard, dtype=np.float32)
+    sc = cm.slot_columns(names)
+    items = make_items(offs)
+    q_ref, it_ref, _ = orc.ik_solve(pos, quat, sc, items)
+    q, it, _ = eng.ik_solve(torch.from_numpy(pos).to(dev), torch.from_numpy(quat).to(dev), sc, items)
+    q, it = q.cpu().numpy(), it.cpu().numpy()
+    assert not np.isnan(q).any()
+    assert (it >> 30).max() == 0, "a QP hit its iteration cap"
+    assert _qpos_diff(q, q_ref) < 1e-6, _qpos_diff(q, q_ref)
+    assert np.array_equal(it, it_ref)
