@@ -30,6 +30,7 @@ struct FkTree {     // device arrays, [nbody]
 };
 
 __device__ __forceinline__ void fk_quat_mul(const float a[4], const float b[4], float o[4]) {
+#pragma clang fp contract(off)
   // torch_utils.quat_mul (xyzw), same operation order
   const float x1 = a[0], y1 = a[1], z1 = a[2], w1 = a[3], x2 = b[0], y2 = b[1], z2 = b[2], w2 = b[3];
   const float ww = (z1 + x1) * (x2 + y2), yy = (w1 - y1) * (w2 + z2), zz = (w1 + y1) * (w2 - z2);
@@ -40,6 +41,7 @@ __device__ __forceinline__ void fk_quat_mul(const float a[4], const float b[4], 
   o[2] = qq - zz + (z1 + y1) * (w2 - x2);
 }
 __device__ __forceinline__ void fk_quat_rotate(const float q[4], const float v[3], float o[3]) {
+#pragma clang fp contract(off)
   // torch_utils.quat_rotate: v (2w^2-1) + 2w (q x v) + 2 q (q.v)
   const float w = q[3], k = 2.0f * w * w - 1.0f;
   const float cx = q[1] * v[2] - q[2] * v[1], cy = q[2] * v[0] - q[0] * v[2], cz = q[0] * v[1] - q[1] * v[0];
@@ -56,6 +58,7 @@ __global__ void __launch_bounds__(kFkThreads) fk_kernel(FkTree t, const float *_
                                                         int64_t n_frames, float *__restrict__ body_pos,
                                                         float *__restrict__ body_rot, const int64_t *__restrict__ seq_offsets,
                                                         int n_seq, int *__restrict__ min_key) {
+#pragma clang fp contract(off)  // torch does not fuse; also keeps MODE 0 and MODE 1 bit-identical
   extern __shared__ float fk_lds[];  // [nslots][7][kFkThreads]
   const int tid = threadIdx.x;
   const int64_t f = (int64_t)blockIdx.x * kFkThreads + tid;

@@ -1,0 +1,264 @@
+"""``GeneralMotionRetargeting`` -- GMR's retarget API on the MI355X engine.
+
+Same constructor, ``retarget()`` signature, statefulness and error behaviour as the
+reference class (general_motion_retargeting/motion_retarget.py:10-270), so it drops in under
+``scripts/*_to_robot_dataset.py``; plus ``retarget_batch()`` which hands whole clips (or many
+clips) to the frames-batched kernel in one launch.
+
+What is different by construction: the per-frame ``mink.solve_ik`` / MuJoCo / DAQP stack is
+replaced by libgmr_amd.so's HIP kernels (exact box-QP, so ``solver`` only names what the
+reference would have used); ``self.model`` is this package's ``RobotModel`` (kinematic subset
+of the MJCF) rather than a ``mujoco.MjModel``; ``self.configuration`` is a small view object
+exposing ``.q`` / ``.data.qpos``.  There is no CPU fallback: without the native library and
+a HIP device the constructor raises.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from scipy.spatial.transform import Rotation as R
+
+from ._native import IKParams, WORK_ITEM_DTYPE
+from .engine import Engine
+from .ik_config import load_ik_config
+from .mjcf import load_robot
+from .model import compile_model
+from .params import IK_CONFIG_DICT, ROBOT_XML_DICT
+from .schedule import make_items
+
+
+class _Data:
+    def __init__(self, owner):
+        self._o = owner
+
+    @property
+    def qpos(self) -> np.ndarray:
+        return self._o._state.cpu().numpy()[0]
+
+
+class _Configuration:
+    """Stand-in for ``mink.Configuration``: current generalized coordinates only."""
+
+    def __init__(self, owner):
+        self._o = owner
+        self.model = owner.model
+        self.data = _Data(owner)
+
+    @property
+    def q(self) -> np.ndarray:
+        return self.data.qpos.copy()
+
+
+class GeneralMotionRetargeting:
+    """General Motion Retargeting (GMR) on gfx950."""
+
+    def __init__(
+        self,
+        src_human: str,
+        tgt_robot: str,
+        actual_human_height: float = None,
+        solver: str = "daqp",
+        damping: float = 5e-1,
+        verbose: bool = False,
+        device: int = 0,
+    ) -> None:
+        # robot model (motion_retarget.py:24-27)
+        self.xml_file = str(ROBOT_XML_DICT[tgt_robot])
+        if verbose:
+            print("Use robot model: ", self.xml_file)
+        self.model = load_robot(self.xml_file, name=tgt_robot)
+        # IK config (:30-33)
+        cfg_path = IK_CONFIG_DICT[src_human][tgt_robot]
+        ik_config = load_ik_config(cfg_path)
+        if verbose:
+            print("Use IK config: ", cfg_path)
+        self._cm = compile_model(self.model, ik_config, actual_human_height)
+        ratio = self._cm.ratio
+
+        self.ik_match_table1 = ik_config.ik_match_table1
+        self.ik_match_table2 = ik_config.ik_match_table2
+        self.human_root_name = ik_config.human_root_name
+        self.robot_root_name = ik_config.robot_root_name
+        self.use_ik_match_table1 = ik_config.use_ik_match_table1
+        self.use_ik_match_table2 = ik_config.use_ik_match_table2
+        self.human_scale_table = {k: v * ratio for k, v in ik_config.human_scale_table.items()}  # :42-43
+        self.ground = ik_config.ground_height * np.array([0, 0, 1])
+        self.max_iter = 10
+        self.solver = solver
+        self.damping = damping
+
+        # offsets keyed by human body name, non-zero-weight entries only (:80-114)
+        self.pos_offsets1, self.rot_offsets1, self.pos_offsets2, self.rot_offsets2 = {}, {}, {}, {}
+        for tab, po, ro in ((ik_config.table1, self.pos_offsets1, self.rot_offsets1), (ik_config.table2, self.pos_offsets2, self.rot_offsets2)):
+            for t in tab:
+                if t.pos_weight != 0 or t.rot_weight != 0:
+                    po[t.human] = np.array(t.pos_offset) - self.ground
+                    ro[t.human] = R.from_quat(t.rot_offset, scalar_first=True)
+        self.tasks1 = [t.frame for t in self._cm.tasks[0]]
+        self.tasks2 = [t.frame for t in self._cm.tasks[1]]
+
+        self._engine = Engine(self._cm, device)
+        self.device = self._engine.device
+        self.setup_retarget_configuration()
+
+    # ------------------------------------------------------------------ state
+    def setup_retarget_configuration(self):
+        """Reset to ``qpos0`` (what a fresh ``mink.Configuration(model)`` holds, :75)."""
+        self._state = torch.from_numpy(self.model.qpos0.copy()).to(self.device).reshape(1, -1)
+        self.configuration = _Configuration(self)
+        self.scaled_human_data = None
+        self._col_cache: Dict[Tuple[str, ...], np.ndarray] = {}
+        self._item1 = np.zeros(1, dtype=WORK_ITEM_DTYPE)
+        self._item1["n_out"] = 1
+        self._item1["init_row"] = 0
+        self._item1["final_row"] = 0
+
+    def _params(self, offset_to_ground: bool) -> IKParams:
+        return IKParams(damping=self.damping, max_iter=self.max_iter, offset_to_ground=int(bool(offset_to_ground)))
+
+    def _columns(self, names: Sequence[str]) -> np.ndarray:
+        key = tuple(names)
+        if key not in self._col_cache:
+            self._col_cache[key] = self._cm.slot_columns(names)
+        return self._col_cache[key]
+
+    # ------------------------------------------------------------------ per-frame API (drop-in)
+    def update_targets(self, human_data, offset_to_ground=False):
+        """Host-side target preparation, kept for callers that read ``scaled_human_data`` (:117-124).
+        The solver itself prepares targets on the GPU from the raw key-points."""
+        human_data = self.to_numpy(human_data)
+        human_data = self.scale_human_data(human_data, self.human_root_name, self.human_scale_table)
+        human_data = self.offset_human_data(human_data, self.pos_offsets1, self.rot_offsets1)
+        if offset_to_ground:
+            human_data = self.offset_human_data_to_ground(human_data)
+        self.scaled_human_data = human_data
+
+    def retarget(self, human_data, offset_to_ground=False):
+        """One frame, warm-started from the previous call; returns a fresh ``qpos`` copy (:139-185)."""
+        human_data = self.to_numpy(human_data)  # mutates the caller's dict like the reference (:203-206)
+        names = list(human_data.keys())
+        cols = self._columns(names)  # KeyError exactly where the reference raises
+        pos = np.stack([np.asarray(human_data[n][0], dtype=np.float64).reshape(3) for n in names])[None]
+        quat = np.stack([np.asarray(human_data[n][1], dtype=np.float64).reshape(4) for n in names])[None]
+        self._last_human_data = human_data
+        self._last_offset_to_ground = offset_to_ground
+        self.scaled_human_data = _LazyScaled(self)
+        out, iters, fin = self._engine.ik_solve(
+            torch.from_numpy(pos).to(self.device), torch.from_numpy(quat).to(self.device), cols, self._item1,
+            params=self._params(offset_to_ground), qpos_init=self._state, n_final=1)
+        self._state = fin
+        q = out.cpu().numpy()[0]
+        self.last_num_solves = int(iters.cpu().numpy()[0]) & 0x3FFFFFFF
+        if not np.all(np.isfinite(q)):
+            raise FloatingPointError("retarget produced non-finite qpos")
+        return q.copy()
+
+    # ------------------------------------------------------------------ batched API
+    def retarget_batch(self, pos, quat, body_names: Sequence[str], seq_offsets=None, chunk: int = 0, burn_in: int = 0,
+                       offset_to_ground: bool = False, return_iters: bool = False):
+        """Retarget whole clips in one launch.
+
+        pos ``[N, B, 3]`` (m), quat ``[N, B, 4]`` (wxyz), float32/float64, numpy or CUDA torch; ``body_names`` names the
+        B columns; ``seq_offsets [S+1]`` delimits independent clips (default: one clip).  Every clip starts from
+        ``qpos0`` like a fresh reference object.  ``chunk``/``burn_in`` enable time-chunking (see schedule.py).
+        Returns qpos ``[N, nq]`` float64 (same container kind as the input) and, optionally, solves per frame.
+        """
+        is_np = isinstance(pos, np.ndarray)
+        tpos = torch.from_numpy(np.ascontiguousarray(pos)) if is_np else pos
+        tquat = torch.from_numpy(np.ascontiguousarray(quat)) if isinstance(quat, np.ndarray) else quat
+        tpos, tquat = tpos.to(self.device), tquat.to(self.device)
+        N = int(tpos.shape[0])
+        if seq_offsets is None:
+            seq_offsets = [0, N]
+        offs = np.asarray(seq_offsets, dtype=np.int64)
+        if offs[0] != 0 or offs[-1] != N:
+            raise ValueError("seq_offsets must span [0, N]")
+        items = make_items(offs, chunk=chunk, burn_in=burn_in)
+        out, iters, _ = self._engine.ik_solve(tpos, tquat, self._columns(list(body_names)), items, params=self._params(offset_to_ground))
+        if is_np:
+            out = out.cpu().numpy()
+            iters = iters.cpu().numpy() if iters is not None else None
+        return (out, iters) if return_iters else out
+
+    # ------------------------------------------------------------------ helpers mirrored from the reference
+    def to_numpy(self, human_data):
+        for body_name in human_data.keys():
+            human_data[body_name] = [np.asarray(human_data[body_name][0]), np.asarray(human_data[body_name][1])]
+        return human_data
+
+    def scale_human_data(self, human_data, human_root_name, human_scale_table):
+        """Root scaled about the world origin, other bodies about the root; unlisted bodies dropped (:209-232)."""
+        root_pos, root_quat = human_data[human_root_name]
+        scaled_root_pos = human_scale_table[human_root_name] * root_pos
+        out = {human_root_name: (scaled_root_pos, root_quat)}
+        for body_name in human_data.keys():
+            if body_name not in human_scale_table or body_name == human_root_name:
+                continue
+            out[body_name] = ((human_data[body_name][0] - root_pos) * human_scale_table[body_name] + scaled_root_pos, human_data[body_name][1])
+        return out
+
+    def offset_human_data(self, human_data, pos_offsets, rot_offsets):
+        """Rotation offset first, then the position offset in the updated local frame (:234-250)."""
+        out = {}
+        for body_name in human_data.keys():
+            pos, quat = human_data[body_name]
+            rot = R.from_quat(quat, scalar_first=True) * rot_offsets[body_name]
+            out[body_name] = [pos + rot.apply(pos_offsets[body_name]), rot.as_quat(scalar_first=True)]
+        return out
+
+    def offset_human_data_to_ground(self, human_data):
+        """Shift everything so the lowest foot sits 0.1 m above z = 0 (:252-270)."""
+        lowest = np.inf
+        for body_name in human_data.keys():
+            if "Foot" not in body_name and "foot" not in body_name:
+                continue
+            lowest = min(lowest, human_data[body_name][0][2])
+        return {k: [v[0] - np.array([0, 0, lowest]) + np.array([0, 0, 0.1]), v[1]] for k, v in human_data.items()}
+
+
+class _LazyScaled(dict):
+    """``scaled_human_data`` computed on first access (only viewers read it; smplx_to_robot.py:133)."""
+
+    def __init__(self, owner: GeneralMotionRetargeting):
+        super().__init__()
+        self._owner, self._done = owner, False
+
+    def _fill(self):
+        if not self._done:
+            o = self._owner
+            d = o.scale_human_data(o._last_human_data, o.human_root_name, o.human_scale_table)
+            d = o.offset_human_data(d, o.pos_offsets1, o.rot_offsets1)
+            if o._last_offset_to_ground:
+                d = o.offset_human_data_to_ground(d)
+            super().update(d)
+            self._done = True
+
+    def __getitem__(self, k):
+        self._fill()
+        return super().__getitem__(k)
+
+    def __iter__(self):
+        self._fill()
+        return super().__iter__()
+
+    def keys(self):
+        self._fill()
+        return super().keys()
+
+    def items(self):
+        self._fill()
+        return super().items()
+
+    def values(self):
+        self._fill()
+        return super().values()
+
+    def __len__(self):
+        self._fill()
+        return super().__len__()
+
+    def __contains__(self, k):
+        self._fill()
+        return super().__contains__(k)

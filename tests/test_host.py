@@ -1,0 +1,171 @@
+"""CPU-only tests of the host logic: MJCF/IK-config compilers, packs, blob, scheduling, C-ABI exports."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from gmr_amd import params
+from gmr_amd.ik_config import load_ik_config
+from gmr_amd.mjcf import MjcfError, load_mjcf, load_robot
+from gmr_amd.model import HEADER_BYTES, compile_model
+from gmr_amd.schedule import make_items, partition_clips
+from tests.util import CONFIG_ROBOTS, compiled
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_size_matches_c_struct():
+    # 4 u32 + 12 i32 + 23 u32 + 3 u32 = 42 words
+    assert HEADER_BYTES == 42 * 4
+
+
+@pytest.mark.parametrize("robot", CONFIG_ROBOTS)
+def test_expected_sizes(robot):
+    exp = {"unitree_g1": (38, 36, 35), "unitree_g1_with_hands": (52, 50, 49), "booster_t1": (32, 28, 27),
+           "stanford_toddy": (33, 29, 28), "fourier_n1": (29, 30, 29), "engineai_pm01": (29, 31, 30)}[robot]
+    rob = compiled("smplx", robot).robot
+    assert (rob.nbody, rob.nq, rob.nv) == exp
+    assert rob.jnt_limited[rob.hinge_bodies()].all()
+    assert np.allclose(np.linalg.norm(rob.body_quat, axis=1), 1.0)
+    assert len(compiled("smplx", robot).tasks[0]) == 14
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+@pytest.mark.parametrize("robot", sorted(set(params._ROBOT_XML_REL) - {"galaxea_r1pro"}))
+def test_packs_are_fresh(robot, monkeypatch):
+    """The shipped packs equal what the MJCF compiler produces from the reference's XML today."""
+    monkeypatch.delenv("GMR_ROOT", raising=False)
+    pack = load_robot(params.ROBOT_XML_DICT[robot])
+    xml = load_mjcf(os.path.join(REF, "assets", params._ROBOT_XML_REL[robot]), name=robot)
+    assert pack.body_names == xml.body_names
+    for f in ("parent", "body_pos", "body_quat_raw", "jnt_type", "jnt_axis_raw", "jnt_range", "jnt_limited", "qpos_adr"):
+        np.testing.assert_array_equal(getattr(pack, f), getattr(xml, f))
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+def test_gmr_root_switches_registry(monkeypatch):
+    monkeypatch.setenv("GMR_ROOT", REF)
+    assert str(params.ROBOT_XML_DICT["unitree_g1"]).endswith("g1_mocap_29dof.xml")
+    assert str(params.IK_CONFIG_DICT["bvh"]["unitree_g1"]).endswith("bvh_to_g1.json")
+    a = load_ik_config(params.IK_CONFIG_DICT["smplx"]["engineai_pm01"])
+    monkeypatch.delenv("GMR_ROOT")
+    assert str(params.ROBOT_XML_DICT["unitree_g1"]).endswith("unitree_g1.json")
+    b = load_ik_config(params.IK_CONFIG_DICT["smplx"]["engineai_pm01"])
+    assert a.to_dict()["tables"] == b.to_dict()["tables"] and a.human_scale_table == b.human_scale_table
+
+
+def test_registry_keyerrors():
+    with pytest.raises(KeyError):
+        params.ROBOT_XML_DICT["no_such_robot"]
+    with pytest.raises(KeyError):
+        params.IK_CONFIG_DICT["smplx"]["no_such_robot"]
+    with pytest.raises(KeyError):
+        params.IK_CONFIG_DICT["nope"]
+
+
+def test_unsupported_model_is_rejected(tmp_path):
+    p = tmp_path / "m.xml"
+    p.write_text('<mujoco><compiler angle="radian"/><worldbody><body name="a"><freejoint/>'
+                 '<body name="b"><joint type="slide" axis="0 0 1"/></body></body></worldbody></mujoco>')
+    with pytest.raises(MjcfError):
+        load_mjcf(str(p))
+
+
+def test_mjcf_defaults_degrees_and_comments(tmp_path):
+    p = tmp_path / "m.xml"
+    p.write_text(
+        '<mujoco model="t"><compiler angle="degree"/><default><joint axis="0 1 0"/><default class="k"><joint range="-90 90"/></default></default>'
+        '<worldbody><body name="root" pos="0 0 1"><joint type="free"/>'
+        '<!-- <joint name="ghost"/> -->'
+        '<body name="a" childclass="k" pos="0 0 -0.5" quat="2 0 0 0"><joint name="ja"/>'
+        '<body name="b"><joint name="jb" class="main" axis="3 0 0" range="-10 20"/></body></body>'
+        '<body name="c"/></body></worldbody><worldbody><light/></worldbody></mujoco>')
+    m = load_mjcf(str(p))
+    assert m.body_names == ["root", "a", "b", "c"] and m.parent.tolist() == [-1, 0, 1, 0]
+    assert (m.nq, m.nv) == (9, 8)
+    np.testing.assert_allclose(m.jnt_range[1], np.deg2rad([-90, 90]))
+    np.testing.assert_allclose(m.jnt_axis[1], [0, 1, 0])
+    np.testing.assert_allclose(m.jnt_axis[2], [1, 0, 0])
+    np.testing.assert_allclose(m.jnt_range[2], np.deg2rad([-10, 20]))
+    np.testing.assert_allclose(m.body_quat[1], [1, 0, 0, 0])
+    np.testing.assert_allclose(m.body_quat_raw[1], [2, 0, 0, 0])
+    np.testing.assert_allclose(m.qpos0[:7], [0, 0, 1, 1, 0, 0, 0])
+
+
+def test_reference_quirks_in_compiled_model():
+    cm = compiled("smplx", "engineai_pm01")
+    cfg = cm.config
+    # quirk 1: table-2 offsets exist in the config but only table-1 offsets reach the blob (motion_retarget.py:121)
+    t1 = {t.frame: t for t in cfg.table1}
+    t2 = {t.frame: t for t in cfg.table2}
+    assert t1["LINK_ELBOW_PITCH_L"].rot_offset != t2["LINK_ELBOW_PITCH_L"].rot_offset
+    s = cm.slot_names.index(t1["LINK_ELBOW_PITCH_L"].human)
+    q = np.array(t1["LINK_ELBOW_PITCH_L"].rot_offset)
+    np.testing.assert_allclose(cm.slot_rot_off[s], q / np.linalg.norm(q))
+    # height ratio scales every scale-table entry
+    cm2 = compiled("smplx", "engineai_pm01", 1.6)
+    np.testing.assert_allclose(cm2.slot_scale, cm.slot_scale * 1.6 / cfg.human_height_assumption)
+
+
+def test_slot_columns_keyerrors():
+    cm = compiled("smplx", "unitree_g1")
+    names = list(cm.slot_names)
+    cols = cm.slot_columns(names + ["jaw", "left_eye"])
+    assert cols.tolist() == list(range(len(names)))
+    with pytest.raises(KeyError):
+        cm.slot_columns([n for n in names if n != "pelvis"])
+    with pytest.raises(KeyError):
+        cm.slot_columns([n for n in names if n != "left_wrist"])
+
+
+def test_make_items_and_partition():
+    it = make_items([0, 5, 5, 12])
+    assert it["frame_begin"].tolist() == [0, 5] and it["n_out"].tolist() == [5, 7] and it["n_burn"].tolist() == [0, 0]
+    it = make_items([0, 10], chunk=4, burn_in=3)
+    assert it["frame_begin"].tolist() == [0, 1, 5] and it["n_burn"].tolist() == [0, 3, 3] and it["n_out"].tolist() == [4, 4, 2]
+    covered = np.concatenate([np.arange(r["frame_begin"] + r["n_burn"], r["frame_begin"] + r["n_burn"] + r["n_out"]) for r in it])
+    assert covered.tolist() == list(range(10))
+    with pytest.raises(ValueError):
+        make_items([0, 5, 3])
+    parts = partition_clips([10, 3, 8, 8, 1, 7], 3)
+    assert sorted(sum(parts, [])) == list(range(6))
+    loads = [sum([10, 3, 8, 8, 1, 7][i] for i in p) for p in parts]
+    assert max(loads) - min(loads) <= 4 and max(loads) <= 15
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    """libgmr_amd.so loads (hipcc cross-compiled, no GPU needed) and exports every function in include/gmr_amd.h."""
+    from gmr_amd import _native
+    from gmr_amd.build import build_lib
+    build_lib()
+    with open(os.path.join(ROOT, "include", "gmr_amd.h")) as f:
+        src = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    declared = sorted(set(re.findall(r"\b(gmr_[a-z_]+)\s*\(", src)))
+    assert set(declared) == set(_native.EXPORTS)
+    lib = _native.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.gmr_abi_version() == 1
+    assert ctypes.sizeof(_native.IKParams) == 48 and _native.WORK_ITEM_DTYPE.itemsize == 24
+
+
+def test_model_create_fails_loudly_without_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from gmr_amd import _native
+    lib = _native.load()
+    cm = compiled("smplx", "unitree_g1")
+    err = ctypes.create_string_buffer(256)
+    h = lib.gmr_model_create(cm.blob, len(cm.blob), 0, err, len(err))
+    assert not h and b"device" in err.value.lower()
+    bad = bytearray(cm.blob)
+    bad[0] ^= 0xFF
+    h = lib.gmr_model_create(bytes(bad), len(bad), 0, err, len(err))
+    assert not h and b"magic" in err.value
+    from gmr_amd.engine import Engine, EngineError
+    with pytest.raises(EngineError):
+        Engine(cm, 0)
