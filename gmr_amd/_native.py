@@ -10,7 +10,9 @@ import os
 
 import numpy as np
 
-from .build import LIB_PATH
+from .build import LIB_PATH as _DEFAULT_LIB_PATH
+
+LIB_PATH = os.environ.get("GMR_AMD_LIB") or _DEFAULT_LIB_PATH  # override only for A/B diagnostics of variant builds
 
 ABI_VERSION = 1
 GMR_DTYPE_F32, GMR_DTYPE_F64 = 0, 1

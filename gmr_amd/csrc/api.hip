@@ -29,12 +29,14 @@ struct gmr_model {
   void *dev = nullptr;
   size_t dev_bytes = 0;
   gmr::DevModel dm{};
+  const gmr::DevModel *dm_dev = nullptr;  // the same struct in device memory (kernels read it through scalar loads)
   gmr::FkTree fk{};
   gmr::LdsLayout lay{};
   int nvp = 0, n_act = 0, lds_bytes = 0, fk_lds_bytes = 0;
   // grow-only workspace for per-call scheduling data
   void *ws = nullptr;
   size_t ws_bytes = 0;
+  unsigned long long *dbg = nullptr;  // diagnostic builds (GMR_IK_STAMPS) only
 };
 
 namespace {
@@ -175,6 +177,29 @@ int build_device_model(gmr_model *m) {
     }
     aanc[i] = mk;
   }
+  // ---- FK pointer-jumping plan: ancestor folded in each round, one byte per round ----
+  int fkrounds = 0;
+  while ((1 << fkrounds) <= maxdepth) ++fkrounds;
+  if (fkrounds > 8) { set_err(m, "tree too deep"); return GMR_EUNSUPPORTED; }
+  std::vector<u64> fkanc(nb, ~0ull);
+  {
+    std::vector<int> anc(parent, parent + nb);
+    for (int r = 0; r < fkrounds; ++r) {
+      std::vector<int> nxt(nb, -1);
+      for (int b = 0; b < nb; ++b) {
+        const u64 byte = anc[b] < 0 ? 0xffull : (u64)anc[b];
+        fkanc[b] = (fkanc[b] & ~(0xffull << (8 * r))) | (byte << (8 * r));
+        nxt[b] = anc[b] < 0 ? -1 : anc[anc[b]];
+      }
+      anc = nxt;
+    }
+    for (int b = 0; b < nb; ++b) if (anc[b] >= 0) { set_err(m, "internal: FK plan incomplete"); return GMR_EINVAL; }
+  }
+  // ---- structurally non-zero off-diagonal pairs of H: (i, j) with dof j strictly above dof i ----
+  std::vector<unsigned short> hpair;
+  for (int i = 0; i < n_act; ++i)
+    for (int j = 0; j < i; ++j)
+      if ((aanc[i] >> j) & 1ull) hpair.push_back((unsigned short)((i << 8) | j));
   // ---- composites per table: dofs sharing the same set of tasks below them share one 6x6 block ----
   std::vector<int> acomp(2 * 64, 0);
   std::vector<unsigned> compmask(2 * 2 * GMR_MAX_TASKS, 0u);
@@ -238,12 +263,13 @@ int build_device_model(gmr_model *m) {
   const size_t o_tbody = P.add(tbody), o_tslot = P.add(tslot), o_twp = P.add(twp), o_twr = P.add(twr);
   const size_t o_abody = P.add(abody), o_akind = P.add(akind), o_aqadr = P.add(aqadr), o_alim = P.add(alim);
   const size_t o_aanc = P.add(aanc), o_arange = P.add(arange), o_acomp = P.add(acomp), o_compmask = P.add(compmask);
+  const size_t o_hpair = P.add(hpair), o_fkanc = P.add(fkanc);
+  const size_t o_dm = P.add(std::vector<gmr::DevModel>(1));
   const size_t o_dofidx = P.add(dofidx), o_src = P.add(src_slot), o_save = P.add(save_slot);
   const size_t o_lpos = P.add(lpos), o_lrot = P.add(lrot), o_jaxis = P.add(jaxis), o_jaxis64 = P.add(jaxis64);
 
   HIP_TRY(m, hipMalloc(&m->dev, P.buf.size()));
   m->dev_bytes = P.buf.size();
-  HIP_TRY(m, hipMemcpy(m->dev, P.buf.data(), P.buf.size(), hipMemcpyHostToDevice));
   const uint8_t *D = static_cast<const uint8_t *>(m->dev);
 #define DP(T, off) reinterpret_cast<const T *>(D + (off))
   gmr::DevModel &dm = m->dm;
@@ -255,11 +281,15 @@ int build_device_model(gmr_model *m) {
   dm.tbody = DP(int, o_tbody); dm.tslot = DP(int, o_tslot); dm.twp = DP(double, o_twp); dm.twr = DP(double, o_twr);
   dm.abody = DP(int, o_abody); dm.akind = DP(int, o_akind); dm.aqadr = DP(int, o_aqadr); dm.alimited = DP(int, o_alim);
   dm.aanc = DP(u64, o_aanc); dm.arange = DP(double, o_arange); dm.acomp = DP(int, o_acomp); dm.compmask = DP(unsigned, o_compmask);
+  dm.hpair = DP(unsigned short, o_hpair); dm.npair = (int)hpair.size(); dm.fkanc = DP(u64, o_fkanc); dm.fkrounds = fkrounds;
+  m->dm_dev = DP(gmr::DevModel, o_dm);
   gmr::FkTree &fk = m->fk;
   fk.parent = DP(int, o_parent); fk.dofidx = DP(int, o_dofidx); fk.src_slot = DP(int, o_src); fk.save_slot = DP(int, o_save);
   fk.lpos = DP(float, o_lpos); fk.lrot = DP(float, o_lrot); fk.jaxis = DP(float, o_jaxis); fk.jaxis64 = DP(double, o_jaxis64);
   fk.nbody = nb; fk.ndof = nq - 7; fk.nslots = nslots; fk.pad = 0;
 #undef DP
+  memcpy(P.buf.data() + o_dm, &dm, sizeof(dm));
+  HIP_TRY(m, hipMemcpy(m->dev, P.buf.data(), P.buf.size(), hipMemcpyHostToDevice));
   m->fk_lds_bytes = std::max(1, nslots) * 7 * gmr::kFkThreads * (int)sizeof(float);
 
   // ---- LDS layout of the IK kernel (doubles) ----
@@ -270,6 +300,10 @@ int build_device_model(gmr_model *m) {
   L.tp = o; o += 3 * ns + (ns & 1);
   L.tq = o; o += 4 * ns;
   L.S = o; o += 6 * nvp;
+  L.F = o; o += 6 * nvp;
+  L.Lb = o; o += 128;  // two 64-entry broadcast rows of the Cholesky
+  L.bodyc = o; o += gmr::kBodyC * nb;
+  L.pairs = o; o += ((int)hpair.size() + 3) / 4 + (((int)hpair.size() + 3) / 4 & 1);
   L.xpos = o; L.H = o;
   int r = o;
   r += 3 * nb + (nb & 1);
@@ -342,6 +376,7 @@ void gmr_model_destroy(gmr_model *m) {
   if (m->device >= 0) (void)hipSetDevice(m->device);
   if (m->dev) (void)hipFree(m->dev);
   if (m->ws) (void)hipFree(m->ws);
+  if (m->dbg) (void)hipFree(m->dbg);
   delete m;
 }
 
@@ -402,6 +437,10 @@ int gmr_ik_solve(gmr_model *m, const void *human_pos, const void *human_quat, in
   L.items = static_cast<const gmr_work_item *>(m->ws);
   L.qinit = qpos_init; L.qfinal = qpos_final; L.qout = qpos_out; L.iters = iters_out;
   L.in_f64 = in_dtype == GMR_DTYPE_F64; L.n_cols = n_cols; L.n_items = n_items; L.prm = *params;
+#ifdef GMR_IK_STAMPS
+  if (!m->dbg) { HIP_TRY(m, hipMalloc(&m->dbg, 16 * sizeof(unsigned long long))); HIP_TRY(m, hipMemset(m->dbg, 0, 16 * sizeof(unsigned long long))); }
+#endif
+  L.dbg = m->dbg;
   switch (m->nvp) {
     case 32: launch_ik<32>(m, L, st); break;
     case 36: launch_ik<36>(m, L, st); break;
@@ -456,5 +495,16 @@ int gmr_fk_min_height(gmr_model *m, const float *root_pos, const float *root_rot
   HIP_TRY(m, hipGetLastError());
   return GMR_OK;
 }
+
+#ifdef GMR_IK_STAMPS
+/* diagnostic builds only: read and clear the per-phase cycle sums */
+int gmr_debug_read_stamps(gmr_model *m, unsigned long long *out16) {
+  if (!m || !m->dbg) return GMR_EINVAL;
+  HIP_TRY(m, hipDeviceSynchronize());
+  HIP_TRY(m, hipMemcpy(out16, m->dbg, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIP_TRY(m, hipMemset(m->dbg, 0, 16 * sizeof(unsigned long long)));
+  return GMR_OK;
+}
+#endif
 
 }  // extern "C"

@@ -37,6 +37,22 @@ namespace gmr {
 
 typedef unsigned long long u64;
 
+#ifdef GMR_IK_STAMPS  // diagnostic build only: per-phase cycle shares (tools/ik_stamps.py); never in the shipped library
+#define GMR_STAMP(i) do { const u64 t_ = __builtin_readcyclecounter(); stamp_acc[i] += t_ - stamp_last; stamp_last = t_; } while (0)
+#else
+#define GMR_STAMP(i) do { } while (0)
+#endif
+
+#ifndef GMR_QP_LDS_BCAST
+#define GMR_QP_LDS_BCAST 1
+#endif
+#ifndef GMR_QP_GROUP
+#define GMR_QP_GROUP 6
+#endif
+#ifndef GMR_IK_WAVES_PER_SIMD
+#define GMR_IK_WAVES_PER_SIMD 2
+#endif
+
 constexpr int kBT = 27;  // doubles per task block: LL(6) LA(9) AA(6) g(6)
 constexpr double kLieEps = 1e-10;  // mink.lie.utils.get_epsilon(float64)
 
@@ -60,10 +76,13 @@ struct DevModel {
   const double *arange;                         // [64][2]
   const int *acomp;                             // [2][64] composite node of the dof per table
   const unsigned *compmask;                     // [2][GMR_MAX_TASKS*2] tasks summed into each composite
+  const unsigned short *hpair;                  // [npair] (i << 8) | j for every dof j strictly above dof i
+  const u64 *fkanc;                             // [nbody] byte r = ancestor folded in FK round r (0xff: none)
+  int npair, fkrounds;
 };
 
 struct LdsLayout {
-  int q, tp, tq, S, xpos, xquat, B, Bc, H, total_doubles;  // H aliases [xpos, xquat, B, Bc] (dead during the QP)
+  int q, tp, tq, S, F, Lb, bodyc, pairs, xpos, xquat, B, Bc, H, total_doubles;  // H aliases [xpos, xquat, B, Bc] (dead during the QP)
 };
 
 struct IkLaunch {
@@ -75,7 +94,15 @@ struct IkLaunch {
   int *iters;
   int in_f64, n_cols, n_items, pad;
   gmr_ik_params prm;
+  u64 *dbg;  // [16] phase cycle sums, diagnostic builds only
 };
+
+// Opaque to the optimiser: values derived from it cannot be hoisted out of the enclosing loop.  Used on indices of
+// per-solve table look-ups so that LICM does not turn them into dozens of VGPRs that stay live across the QP.
+__device__ __forceinline__ int launder(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
 
 // ------------------------------------------------------------------ wave helpers (wave = 64)
 __device__ __forceinline__ double rdlane(double v, int lane) {  // lane: wave-uniform
@@ -83,31 +110,92 @@ __device__ __forceinline__ double rdlane(double v, int lane) {  // lane: wave-un
   int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ u64 rdlane_u64(u64 v, int lane) {
-  unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, lane);
-  unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
-  return ((u64)hi << 32) | lo;
+// One DPP hop of a 64-bit value: lanes without a source keep `ident` (row_shr / row_bcast, bound_ctrl off).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_hop(double v, double ident) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(ident), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ double fast_rsqrt(double x) {  // ~1 ulp after two Newton steps
+// Wave reductions in the VALU (6 DPP hops, no LDS round trips); result broadcast from lane 63.
+#define GMR_WAVE_REDUCE(NAME, IDENT, OP)                                 \
+  __device__ __forceinline__ double NAME(double v) {                     \
+    const double id = (IDENT);                                           \
+    v = OP(v, dpp_hop<0x111, 0xf>(v, id)); /* row_shr:1 */               \
+    v = OP(v, dpp_hop<0x112, 0xf>(v, id)); /* row_shr:2 */               \
+    v = OP(v, dpp_hop<0x114, 0xf>(v, id)); /* row_shr:4 */               \
+    v = OP(v, dpp_hop<0x118, 0xf>(v, id)); /* row_shr:8 */               \
+    v = OP(v, dpp_hop<0x142, 0xa>(v, id)); /* row_bcast:15 -> rows 1,3 */ \
+    v = OP(v, dpp_hop<0x143, 0xc>(v, id)); /* row_bcast:31 -> rows 2,3 */ \
+    return rdlane(v, 63);                                                \
+  }
+__device__ __forceinline__ double op_add(double a, double b) { return a + b; }
+__device__ __forceinline__ double op_min(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ double op_max(double a, double b) { return fmax(a, b); }
+GMR_WAVE_REDUCE(wave_sum, 0.0, op_add)
+GMR_WAVE_REDUCE(wave_min, INFINITY, op_min)
+GMR_WAVE_REDUCE(wave_max, -INFINITY, op_max)
+
+// ------------------------------------------------------------------ lean float64 math (<= ~1 ulp, no slow paths)
+__device__ __forceinline__ double fast_rsqrt(double x) {
   double r = __builtin_amdgcn_rsq(x);
   r = r * (1.5 - 0.5 * x * r * r);
   r = r * (1.5 - 0.5 * x * r * r);
   return r;
+}
+__device__ __forceinline__ double fast_sqrt(double x) {  // x >= 0
+  const double r = fast_rsqrt(x);
+  double s = x * r;
+  s = fma(0.5 * r, fma(-s, s, x), s);
+  return x > 0.0 ? s : 0.0;
+}
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(r, fma(-x, r, 1.0), r);
+  r = fma(r, fma(-x, r, 1.0), r);
+  return r;
+}
+__device__ __forceinline__ double fast_div(double a, double b) {
+  const double r = fast_rcp(b);
+  const double q = a * r;
+  return fma(r, fma(-q, b, a), q);
+}
+// sin and cos for |x| <~ 4 (joint half-angles, |dw|/2): Cody-Waite by pi/2, fdlibm kernels.
+__device__ __forceinline__ void sincos_small(double x, double *sn, double *cs) {
+  const double k = rint(x * 6.36619772367581382433e-01);
+  double r = fma(-k, 1.57079632673412561417e+00, x);
+  r = fma(-k, 6.07710050630396597660e-11, r);
+  r = fma(-k, 2.02226624879595063154e-21, r);
+  const double z = r * r;
+  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                       -1.98412698298579493134e-04), 8.33333333332248946124e-03), -1.66666666666666324348e-01);
+  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                                       2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+  const double s = fma(r * z, ps, r);
+  const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
+  const int n = (int)k & 3;
+  const double s1 = (n & 1) ? c : s, c1 = (n & 1) ? s : c;
+  *sn = (n & 2) ? -s1 : s1;
+  *cs = ((n + 1) & 2) ? -c1 : c1;
+}
+// atan2(y, x) for y >= 0, x >= 0, not both zero (fdlibm atan on [0,1] + reflection)
+__device__ __forceinline__ double atan2_pos(double y, double x) {
+  const bool swap = y > x;
+  const double a = swap ? x : y, b = swap ? y : x;
+  const double t0 = fast_div(a, b);  // in [0,1]
+  const bool lo = t0 < 0.4375, mid = t0 < 0.6875;
+  const double num = lo ? t0 : (mid ? 2.0 * t0 - 1.0 : t0 - 1.0);
+  const double den = lo ? 1.0 : (mid ? 2.0 + t0 : t0 + 1.0);
+  const double t = lo ? t0 : fast_div(num, den);
+  const double z = t * t, w = z * z;
+  const double s1 = z * fma(w, fma(w, fma(w, fma(w, fma(w, 1.62858201153657823623e-02, 4.97687799461593236017e-02), 6.66107313738753120669e-02),
+                                          9.09088713343650656196e-02), 1.42857142725034663711e-01), 3.33333333333329318027e-01);
+  const double s2 = w * fma(w, fma(w, fma(w, fma(w, -3.65315727442169155270e-02, -5.83357013379057348645e-02), -7.69187620504482999495e-02),
+                                   -1.11111104054623557880e-01), -1.99999999998764832476e-01);
+  const double hi = lo ? 0.0 : (mid ? 4.63647609000806093515e-01 : 7.85398163397448278999e-01);
+  const double lw = lo ? 0.0 : (mid ? 2.26987774529616870924e-17 : 3.06161699786838301793e-17);
+  const double r = hi - ((t * (s1 + s2) - lw) - t);
+  return swap ? 1.57079632679489655800e+00 - r + 6.12323399573676603587e-17 : r;
 }
 
 // ------------------------------------------------------------------ quaternion / matrix helpers (wxyz)
@@ -120,6 +208,11 @@ __device__ __forceinline__ void qmul(const double a[4], const double b[4], doubl
 }
 __device__ __forceinline__ void qnormalize(double q[4]) {
   double r = fast_rsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  q[0] *= r; q[1] *= r; q[2] *= r; q[3] *= r;
+}
+// renormalise a quaternion that is already unit to rounding (product of unit quaternions): one Newton step from r = 1
+__device__ __forceinline__ void qrenorm(double q[4]) {
+  const double r = fma(-0.5, q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3], 1.5);
   q[0] *= r; q[1] *= r; q[2] *= r; q[3] *= r;
 }
 __device__ __forceinline__ void q2mat(const double q[4], double R[9]) {  // mju_quat2Mat
@@ -147,47 +240,62 @@ __device__ __forceinline__ void cross(const double a[3], const double b[3], doub
   o[2] = a[0] * b[1] - a[1] * b[0];
 }
 
-// per-lane constants of the body this lane owns in the FK phase
-struct BodyConst {
-  int parent, depth, jtype, qadr;
-  double pos[3], quat[4], axis[3];
-};
-
 // ------------------------------------------------------------------ FK (mj_kinematics), lane = body
-// xpos_j = xpos_p + R(xquat_p) pos_j ;  xquat_j = normalize(xquat_p (x) quat_j (x) [cos t/2, sin t/2 axis_j])
-__device__ __forceinline__ void fk_phase(const DevModel &m, const BodyConst &bc, int lane, const double *q, double *xpos,
+// xpos_j = xpos_p + R(xquat_p) pos_j ;  xquat_j = xquat_p (x) quat_j (x) [cos t/2, sin t/2 axis_j]
+// evaluated by pointer jumping instead of walking the tree level by level: every lane holds its body's pose
+// relative to an ancestor and, each round, composes it with that ancestor's own relative pose (which doubles
+// the distance folded), so a chain of depth d needs ceil(log2 d) LDS round trips instead of d.  The ancestor
+// of each round is static per body (m.fkanc, one byte per round, 0xff = already in the world frame).
+// The joint tree (per-body pos / quat / axis / joint type / ancestor plan) is staged in LDS once per wavefront.
+__device__ __forceinline__ void qrot(const double q[4], const double v[3], double o[3]) {  // R(q) v, q unit
+  const double tx = 2.0 * (q[2] * v[2] - q[3] * v[1]), ty = 2.0 * (q[3] * v[0] - q[1] * v[2]), tz = 2.0 * (q[1] * v[1] - q[2] * v[0]);
+  o[0] = v[0] + q[0] * tx + (q[2] * tz - q[3] * ty);
+  o[1] = v[1] + q[0] * ty + (q[3] * tx - q[1] * tz);
+  o[2] = v[2] + q[0] * tz + (q[1] * ty - q[2] * tx);
+}
+constexpr int kBodyC = 12;  // doubles per body in the LDS-staged joint tree: pos(3) quat(4) axis(3) {jtype,qadr} fkanc
+__device__ __forceinline__ void fk_phase(const double *bodyc, int nbody, int nrounds, int lane, const double *q, double *xpos,
                                          double *xquat) {
-  double ql[4] = {1, 0, 0, 0};
-  const bool has = lane < m.nbody;
+  const bool has = lane < nbody;
+  const double *bcst = bodyc + kBodyC * (has ? lane : 0);
+  const long long packed = __double_as_longlong(bcst[10]);
+  const int jtype = (int)(packed & 0xff), qadr = (int)(packed >> 8);
+  const u64 ancs = has ? (u64)__double_as_longlong(bcst[11]) : ~0ull;
+  double pos[3] = {bcst[0], bcst[1], bcst[2]};
+  const double bq[4] = {bcst[3], bcst[4], bcst[5], bcst[6]};
+  const double ax[3] = {bcst[7], bcst[8], bcst[9]};
+  double ql[4] = {bq[0], bq[1], bq[2], bq[3]};
+  if (jtype == GMR_JNT_FREE) {
+    ql[0] = q[3]; ql[1] = q[4]; ql[2] = q[5]; ql[3] = q[6];
+    qnormalize(ql);
+    pos[0] = q[0]; pos[1] = q[1]; pos[2] = q[2];
+  } else if (jtype == GMR_JNT_HINGE) {
+    double s, c;
+    sincos_small(0.5 * q[qadr], &s, &c);
+    const double jq[4] = {c, s * ax[0], s * ax[1], s * ax[2]};
+    qmul(bq, jq, ql);
+  }
   if (has) {
-    if (bc.jtype == GMR_JNT_FREE) {
-      double r[4] = {q[3], q[4], q[5], q[6]};
-      qnormalize(r);
-      xpos[0] = q[0]; xpos[1] = q[1]; xpos[2] = q[2];
-      xquat[0] = r[0]; xquat[1] = r[1]; xquat[2] = r[2]; xquat[3] = r[3];
-    } else if (bc.jtype == GMR_JNT_HINGE) {
-      double s, c;
-      sincos(0.5 * q[bc.qadr], &s, &c);
-      double jq[4] = {c, s * bc.axis[0], s * bc.axis[1], s * bc.axis[2]};
-      qmul(bc.quat, jq, ql);
-    } else {
-      ql[0] = bc.quat[0]; ql[1] = bc.quat[1]; ql[2] = bc.quat[2]; ql[3] = bc.quat[3];
-    }
+    xpos[3 * lane] = pos[0]; xpos[3 * lane + 1] = pos[1]; xpos[3 * lane + 2] = pos[2];
+    xquat[4 * lane] = ql[0]; xquat[4 * lane + 1] = ql[1]; xquat[4 * lane + 2] = ql[2]; xquat[4 * lane + 3] = ql[3];
   }
   __syncthreads();
-  for (int d = 1; d <= m.maxdepth; ++d) {
-    if (has && bc.depth == d) {
-      const int p = bc.parent;
-      double qp[4] = {xquat[4 * p], xquat[4 * p + 1], xquat[4 * p + 2], xquat[4 * p + 3]};
-      double R[9], t[3], qo[4];
-      q2mat(qp, R);
-      mv(R, bc.pos, t);
-      qmul(qp, ql, qo);
-      qnormalize(qo);
-      xpos[3 * lane] = xpos[3 * p] + t[0];
-      xpos[3 * lane + 1] = xpos[3 * p + 1] + t[1];
-      xpos[3 * lane + 2] = xpos[3 * p + 2] + t[2];
-      xquat[4 * lane] = qo[0]; xquat[4 * lane + 1] = qo[1]; xquat[4 * lane + 2] = qo[2]; xquat[4 * lane + 3] = qo[3];
+  const int nr = nrounds;
+  for (int r = 0; r < nr; ++r) {
+    const int a = (int)((ancs >> (8 * r)) & 0xff);
+    const bool act = a != 0xff;
+    const int aa = act ? a : 0;
+    const double qa[4] = {xquat[4 * aa], xquat[4 * aa + 1], xquat[4 * aa + 2], xquat[4 * aa + 3]};
+    const double pa[3] = {xpos[3 * aa], xpos[3 * aa + 1], xpos[3 * aa + 2]};
+    if (act) {
+      double t[3], qo[4];
+      qrot(qa, pos, t);
+      qmul(qa, ql, qo);
+      pos[0] = pa[0] + t[0]; pos[1] = pa[1] + t[1]; pos[2] = pa[2] + t[2];
+      ql[0] = qo[0]; ql[1] = qo[1]; ql[2] = qo[2]; ql[3] = qo[3];
+      if (r == nr - 1 || ((ancs >> (8 * (r + 1))) & 0xff) == 0xff) qrenorm(ql);  // reached the world frame
+      xpos[3 * lane] = pos[0]; xpos[3 * lane + 1] = pos[1]; xpos[3 * lane + 2] = pos[2];
+      xquat[4 * lane] = ql[0]; xquat[4 * lane + 1] = ql[1]; xquat[4 * lane + 2] = ql[2]; xquat[4 * lane + 3] = ql[3];
     }
     __syncthreads();
   }
@@ -195,9 +303,10 @@ __device__ __forceinline__ void fk_phase(const DevModel &m, const BodyConst &bc,
 
 // ------------------------------------------------------------------ residual, lane = task
 // e = Log(T_wb^-1 T_wt) in [v; w] order (mink FrameTask.compute_error, via motion_retarget.py:188-200).
-// Returns |e|^2 contribution of this lane; e is kept in registers for the assembly.
+// Returns this lane's |e|^2; e and (sin, cos) of half the rotation angle stay in registers for the assembly.
+// The half-angle sine/cosine are the relative quaternion's own |v| and |w|, so no trig beyond one atan2.
 __device__ __forceinline__ double task_residual(int body, int slot, const double *xpos, const double *xquat, const double *tp,
-                                                const double *tq, double e[6]) {
+                                                const double *tq, double e[6], double &sh, double &ch) {
   const double qb[4] = {xquat[4 * body], xquat[4 * body + 1], xquat[4 * body + 2], xquat[4 * body + 3]};
   const double qt[4] = {tq[4 * slot], tq[4 * slot + 1], tq[4 * slot + 2], tq[4 * slot + 3]};
   const double qc[4] = {qb[0], -qb[1], -qb[2], -qb[3]};
@@ -210,24 +319,22 @@ __device__ __forceinline__ double task_residual(int body, int slot, const double
   mtv(R, d, t);
   // SO3 log, short side (mink.lie.so3.SO3.log)
   const double w = qr[0], n2 = qr[1] * qr[1] + qr[2] * qr[2] + qr[3] * qr[3];
-  double f;
+  double f, c2;
   if (n2 < kLieEps) {
-    f = 2.0 / w - 2.0 / 3.0 * n2 / (w * w * w);
+    const double iw = fast_rcp(w);
+    f = 2.0 * iw - 2.0 / 3.0 * n2 * iw * iw * iw;
+    sh = fast_sqrt(n2); ch = fabs(w);
   } else {
-    const double n = sqrt(n2);
-    if (fabs(w) < kLieEps) f = (w > 0 ? 1.0 : -1.0) * M_PI / n;
-    else f = 2.0 * atan2(w < 0 ? -n : n, fabs(w)) / n;
+    const double n = fast_sqrt(n2), aw = fabs(w);
+    const double in = fast_rcp(n);
+    if (aw < kLieEps) f = (w > 0 ? 1.0 : -1.0) * M_PI * in;
+    else f = (w < 0 ? -2.0 : 2.0) * atan2_pos(n, aw) * in;
+    sh = n; ch = aw;
   }
   const double om[3] = {f * qr[1], f * qr[2], f * qr[3]};
   const double th2 = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
-  double c2;
   if (th2 < kLieEps) c2 = 1.0 / 12.0;
-  else {
-    const double th = sqrt(th2);
-    double s, c;
-    sincos(0.5 * th, &s, &c);
-    c2 = (1.0 - 0.5 * th * c / s) / th2;
-  }
+  else c2 = (1.0 - 0.5 * fast_sqrt(th2) * ch * fast_rcp(sh)) * fast_rcp(th2);
   // V^-1 t = t - 1/2 om x t + c2 om x (om x t)
   double a[3], b[3];
   cross(om, t, a);
@@ -242,21 +349,19 @@ __device__ __forceinline__ double task_residual(int body, int slot, const double
 // ------------------------------------------------------------------ task block, lane = task
 // A_t = -[[U, V],[0, U]] with U = Jso3^-1 R', V = Bo R' - U [x_b]x (see header); writes
 // LL = wp^2 U'U, LA = wp^2 U'V, AA = wp^2 V'V + wr^2 U'U, g = A_t' W^2 e  -> out[27]; returns |W e|^2.
-__device__ __forceinline__ double task_block(int body, const double *xpos, const double *xquat, const double e[6], double wp,
-                                             double wr, double *out) {
+__device__ __forceinline__ double task_block(int body, const double *xpos, const double *xquat, const double e[6], double sh,
+                                             double ch, double wp, double wr, double *out) {
   const double *u = e, *ph = e + 3;
   const double th2 = ph[0] * ph[0] + ph[1] * ph[1] + ph[2] * ph[2];
   const double pu = ph[0] * u[0] + ph[1] * u[1] + ph[2] * u[2];
   double kap = 0, bet = 0;
   const bool small = th2 < kLieEps;  // mink SE3.ljacinv returns the identity below this threshold
   if (!small) {
-    const double th = sqrt(th2);
-    double s, c;
-    sincos(0.5 * th, &s, &c);
-    const double cot = c / s;
-    kap = (1.0 - 0.5 * th * cot) / th2;
-    const double delta = th / (4.0 * s * s) - 0.5 * cot;
-    bet = (kap - delta / (2.0 * th)) / th2;
+    const double th = fast_sqrt(th2), ith2 = fast_rcp(th2);
+    const double is = fast_rcp(sh), cot = ch * is;
+    kap = (1.0 - 0.5 * th * cot) * ith2;
+    const double delta = 0.25 * th * is * is - 0.5 * cot;
+    bet = (kap - 0.5 * delta * fast_rcp(th)) * ith2;
   }
   // A = I - 1/2 [ph]x + kap (ph ph' - th2 I);  Bo = -1/2 [u]x + kap (ph u' + u ph' - 2 pu I) - 2 bet pu (ph ph' - th2 I)
   double A[9], Bo[9];
@@ -338,10 +443,11 @@ __device__ __forceinline__ void sym6_mul(const double *B, const double m[3], con
 // the unique optimum DAQP returns for mink.solve_ik's QP.  `status` (0 free, 1 at lo, 2 at hi, 3 padding)
 // persists across calls as the warm-started working set.  Returns the iteration count, negative if capped.
 template <int NVP>
-__device__ __forceinline__ int box_qp(int lane, int n_act, const double *Hm, double ci, double lo, double hi, int &status,
+__device__ __forceinline__ int box_qp(int lane, int n_act, const double *Hm, double *Lb, double ci, double lo, double hi, int &status,
                                       double &x_out) {
   const bool real_row = lane < n_act;
-  const bool in_mat = lane < NVP;
+  const int li = lane < NVP ? lane : 0;  // lanes beyond the matrix shadow row 0: they only ever receive broadcasts
+  double *Yb = Lb + 64;
   const u64 real_mask = n_act >= 64 ? ~0ull : ((1ull << n_act) - 1ull);
   double x = 0.0;
   if (real_row) {
@@ -354,46 +460,74 @@ __device__ __forceinline__ int box_qp(int lane, int n_act, const double *Hm, dou
   constexpr int kMaxIt = 6 * NVP + 16;
   int it = 0;
   for (; it < kMaxIt; ++it) {
+    lane = launder(lane);  // keeps the 100+ lane-vs-constant masks of the unrolled loops from being hoisted into (spilled) SGPRs
     const u64 fixed = __ballot(status != 0);
     const u64 fixed_real = fixed & real_mask;
+    const bool mine_fixed = status != 0;
     // right-hand side: free rows -c_i - sum_{j fixed} H_ij x_j ; fixed rows x_i
     double b = -ci;
     for (u64 mm = fixed_real; mm; mm &= mm - 1) {
       const int j = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(mm));
-      const double xj = rdlane(x, j);
-      if (in_mat) b -= Hm[j * NVP + lane] * xj;
+      b -= Hm[j * NVP + li] * rdlane(x, j);
     }
-    if (status != 0) b = x;
+    b = mine_fixed ? x : b;
+    // this lane's row of H, rows/columns of the working set replaced by the identity (straight-line: selects only)
     double R[NVP];
 #pragma unroll
     for (int j = 0; j < NVP; j++) {
-      double v = in_mat ? Hm[j * NVP + lane] : 0.0;
+      const double h = Hm[j * NVP + li];
       const bool fj = (fixed >> j) & 1ull;
-      if (fj || status != 0) v = (j == lane) ? 1.0 : 0.0;
-      R[j] = v;
+      R[j] = (fj || mine_fixed) ? (j == lane ? 1.0 : 0.0) : h;
     }
     double myinv = 1.0;
+#if GMR_QP_LDS_BCAST
+    // Right-looking Cholesky kept symmetric.  Column k of L and y_k = (L^-1 b)_k reach every lane through two
+    // 64-entry LDS rows (one unconditional ds_write_b64 each per lane, then wave-uniform ds_read_b128 pairs), so the
+    // VALU only issues the FMAs.  The forward solve rides along as an extra column (b_i -= l_i y_k).  Lane k uses
+    // l_k = sqrt(d) - 1, which turns its (symmetric) trailing row sqrt(d) L[j][k] into L[j][k]: after step k lane
+    // k's registers j > k hold column k of L, i.e. row k of L', and the backward solve is broadcast-style too.
 #pragma unroll
     for (int k = 0; k < NVP; k++) {
       const double dkk = rdlane(R[k], k);
       const double inv = fast_rsqrt(dkk);
-      double l = R[k] * inv;
-      if (lane == k) { myinv = inv; l = dkk * inv - 1.0; }
-      if (lane < k) l = 0.0;
+      const double lk = R[k] * inv;
+      const double l = lane == k ? dkk * inv - 1.0 : (lane < k ? 0.0 : lk);
+      myinv = lane == k ? inv : myinv;
+      Lb[lane] = l;
+      Yb[lane] = b * inv;
+      __syncthreads();
+      const double yk = Yb[k];
 #pragma unroll
-      for (int j = k + 1; j < NVP; j++) {
-        const double ljk = rdlane(l, j);
-        R[j] -= l * ljk;
+      for (int jj = (k + 1) & ~1; jj < NVP; jj += 2) {
+        const double2 v = *reinterpret_cast<const double2 *>(Lb + jj);
+        if (jj > k) R[jj] -= l * v.x;
+        if (jj + 1 < NVP) R[jj + 1] -= l * v.y;
+        if ((jj / 2) % GMR_QP_GROUP == GMR_QP_GROUP - 1) __builtin_amdgcn_sched_barrier(0);  // bound the broadcast values in flight
       }
-      if (lane > k) R[k] = l;
+      b = lane == k ? yk : b - l * yk;
+      R[k] = lane > k ? lk : R[k];
     }
-    // forward L y = b (rows below k use L[i][k] = R_i[k]); backward L' z = y (rows above k use L[k][i] = R_i[k])
+#else
+#pragma unroll
+    for (int k = 0; k < NVP; k++) {
+      const double dkk = rdlane(R[k], k);
+      const double inv = fast_rsqrt(dkk);
+      const double lk = R[k] * inv;
+      const double l = lane == k ? dkk * inv - 1.0 : (lane < k ? 0.0 : lk);
+      myinv = lane == k ? inv : myinv;
+#pragma unroll
+      for (int j = k + 1; j < NVP; j++) R[j] -= l * rdlane(l, j);
+      R[k] = lane > k ? lk : R[k];
+    }
+    // forward L y = b (rows below k use L[i][k] = R_i[k])
 #pragma unroll
     for (int k = 0; k < NVP; k++) {
       const double yk = rdlane(b * myinv, k);
       const double coef = lane > k ? R[k] : 0.0;
       b = lane == k ? yk : b - coef * yk;
     }
+#endif
+    // backward L' z = y (rows above k use L[k][i] = R_i[k])
 #pragma unroll
     for (int k = NVP - 1; k >= 0; k--) {
       const double zk = rdlane(b * myinv, k);
@@ -404,7 +538,7 @@ __device__ __forceinline__ int box_qp(int lane, int n_act, const double *Hm, dou
     // ratio test along x -> z over the free variables
     double a = 2.0;
     int side = 0;
-    if (status == 0) {
+    if (!mine_fixed) {
       const double d = z - x;
       if (z > hi + 1e-14 && d > 0) { a = (hi - x) / d; side = 2; }
       else if (z < lo - 1e-14 && d < 0) { a = (lo - x) / d; side = 1; }
@@ -414,18 +548,18 @@ __device__ __forceinline__ int box_qp(int lane, int n_act, const double *Hm, dou
       const u64 who = __ballot(a == amin);
       const int blk = (int)__builtin_ctzll(who);
       const double al = fmax(amin, 0.0);
-      if (status == 0) x += al * (z - x);
+      if (!mine_fixed) x += al * (z - x);
       if (lane == blk) { x = side == 2 ? hi : lo; status = side; }
       continue;
     }
-    if (status == 0) x = z;
+    if (!mine_fixed) x = z;
     if (!fixed_real) { ++it; break; }
     // multipliers of the working set: g_j = c_j + sum_i H_ji x_i
     double worst = gtol;
     int rel = -1;
     for (u64 mm = fixed_real; mm; mm &= mm - 1) {
       const int j = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(mm));
-      const double hx = in_mat ? Hm[j * NVP + lane] * x : 0.0;
+      const double hx = lane < NVP ? Hm[j * NVP + li] * x : 0.0;
       const double g = wave_sum(hx) + rdlane(ci, j);
       const int sj = __builtin_amdgcn_readlane(status, j);
       const double viol = sj == 1 ? -g : g;
@@ -440,58 +574,47 @@ __device__ __forceinline__ int box_qp(int lane, int n_act, const double *Hm, dou
 
 // ------------------------------------------------------------------ the kernel
 template <int NVP>
-__global__ void __launch_bounds__(64, 2) ik_kernel(DevModel m, IkLaunch L, LdsLayout lay) {
+__global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const DevModel m, IkLaunch L, LdsLayout lay) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
   double *q = lds + lay.q, *xpos = lds + lay.xpos, *xquat = lds + lay.xquat, *tp = lds + lay.tp, *tq = lds + lay.tq;
-  double *Bt = lds + lay.B, *Bc = lds + lay.Bc, *S = lds + lay.S, *Hm = lds + lay.H;
+  double *Bt = lds + lay.B, *Bc = lds + lay.Bc, *S = lds + lay.S, *F = lds + lay.F, *Hm = lds + lay.H;
+  double *bodyc = lds + lay.bodyc;
+  unsigned short *pairs = reinterpret_cast<unsigned short *>(lds + lay.pairs);
   const gmr_work_item w = L.items[blockIdx.x];
   const gmr_ik_params prm = L.prm;
+#ifdef GMR_IK_STAMPS
+  u64 stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  u64 stamp_last = __builtin_readcyclecounter();
+#endif
+  const int nq = m.nq, n_act = m.n_act, nslot = m.nslot, root_slot = m.root_slot, npair = m.npair, nbody = m.nbody, fkrounds = m.fkrounds;
+  // active-dof constants of this lane (row of the QP); the rest is re-read where it is used
+  const bool real_row = lane < n_act;
+  const int arow = real_row ? lane : 0;
+  const int a_body = m.abody[arow], a_kind = real_row ? m.akind[arow] : -1, a_qadr = m.aqadr[arow], a_lim = real_row ? m.alimited[arow] : 0;
+  const bool is_slot = lane < nslot;
+  const int s_col = L.slot_col[is_slot ? lane : 0], root_col = L.slot_col[root_slot];
+  constexpr int kPairRounds = (NVP * (NVP - 1) / 2 + 63) / 64;
 
-  BodyConst bc;
-  bc.parent = -1; bc.depth = -1; bc.jtype = 0; bc.qadr = -1;
+  // ---- stage the joint tree and the H pair list in LDS (read every solve) ----
+  if (lane < nbody) {
+    double *bcst = bodyc + kBodyC * lane;
 #pragma unroll
-  for (int i = 0; i < 3; i++) { bc.pos[i] = 0; bc.axis[i] = 0; }
-  bc.quat[0] = 1; bc.quat[1] = bc.quat[2] = bc.quat[3] = 0;
-  if (lane < m.nbody) {
-    bc.parent = m.parent[lane]; bc.depth = m.depth[lane]; bc.jtype = m.jtype[lane]; bc.qadr = m.qadr[lane];
+    for (int i = 0; i < 3; i++) { bcst[i] = m.bpos[3 * lane + i]; bcst[7 + i] = m.axis[3 * lane + i]; }
 #pragma unroll
-    for (int i = 0; i < 3; i++) { bc.pos[i] = m.bpos[3 * lane + i]; bc.axis[i] = m.axis[3 * lane + i]; }
-#pragma unroll
-    for (int i = 0; i < 4; i++) bc.quat[i] = m.bquat[4 * lane + i];
+    for (int i = 0; i < 4; i++) bcst[3 + i] = m.bquat[4 * lane + i];
+    bcst[10] = __longlong_as_double((long long)m.jtype[lane] | ((long long)m.qadr[lane] << 8));
+    bcst[11] = __longlong_as_double((long long)m.fkanc[lane]);
   }
-  // active-dof constants of this lane (row of the QP)
-  const bool real_row = lane < m.n_act;
-  int a_body = 0, a_kind = -1, a_qadr = 0, a_lim = 0;
-  u64 a_anc = 0;
-  double a_rlo = 0, a_rhi = 0, a_axis[3] = {0, 0, 0};
-  if (real_row) {
-    a_body = m.abody[lane]; a_kind = m.akind[lane]; a_qadr = m.aqadr[lane]; a_lim = m.alimited[lane];
-    a_anc = m.aanc[lane]; a_rlo = m.arange[2 * lane]; a_rhi = m.arange[2 * lane + 1];
-#pragma unroll
-    for (int i = 0; i < 3; i++) a_axis[i] = m.axis[3 * a_body + i];
-  }
-  // slot constants (target preparation), lane = slot
-  const bool is_slot = lane < m.nslot;
-  double s_scale = 1, s_poff[3] = {0, 0, 0}, s_roff[4] = {1, 0, 0, 0};
-  int s_col = 0, s_foot = 0;
-  if (is_slot) {
-    s_scale = m.sscale[lane]; s_col = L.slot_col[lane]; s_foot = m.sfoot[lane];
-#pragma unroll
-    for (int i = 0; i < 3; i++) s_poff[i] = m.spoff[3 * lane + i];
-#pragma unroll
-    for (int i = 0; i < 4; i++) s_roff[i] = m.sroff[4 * lane + i];
-  }
-  const double root_scale = m.sscale[m.root_slot];
-  const int root_col = L.slot_col[m.root_slot];
-
-  for (int i = lane; i < m.nq; i += 64) q[i] = w.init_row >= 0 ? L.qinit[(size_t)w.init_row * m.nq + i] : m.qpos0[i];
+  for (int i = lane; i < npair; i += 64) pairs[i] = m.hpair[i];
+  for (int i = lane; i < nq; i += 64) q[i] = w.init_row >= 0 ? L.qinit[(size_t)w.init_row * nq + i] : m.qpos0[i];
   int status = real_row ? 0 : 3;
   __syncthreads();
 
   const int nfr = w.n_burn + w.n_out;
   for (int kf = 0; kf < nfr; ++kf) {
     const int64_t f = w.frame_begin + kf;
+    GMR_STAMP(10);
     // ---- target preparation (update_targets: scale_human_data + offset_human_data, table-1 offsets) ----
     {
       double hp[3] = {0, 0, 0}, hq[4] = {1, 0, 0, 0}, rp[3];
@@ -520,19 +643,20 @@ __global__ void __launch_bounds__(64, 2) ik_kernel(DevModel m, IkLaunch L, LdsLa
       double pz = INFINITY;
       double p[3] = {0, 0, 0}, qo[4] = {1, 0, 0, 0}, R[9], g[3];
       if (is_slot) {
+        const double s_scale = m.sscale[lane], root_scale = m.sscale[root_slot];
+        const double s_poff[3] = {m.spoff[3 * lane], m.spoff[3 * lane + 1], m.spoff[3 * lane + 2]};
+        const double s_roff[4] = {m.sroff[4 * lane], m.sroff[4 * lane + 1], m.sroff[4 * lane + 2], m.sroff[4 * lane + 3]};
 #pragma unroll
         for (int i = 0; i < 3; i++)
-          p[i] = (lane == m.root_slot) ? root_scale * rp[i] : (hp[i] - rp[i]) * s_scale + root_scale * rp[i];
-        const double hn = 1.0 / sqrt(hq[0] * hq[0] + hq[1] * hq[1] + hq[2] * hq[2] + hq[3] * hq[3]);
-#pragma unroll
-        for (int i = 0; i < 4; i++) hq[i] *= hn;
+          p[i] = (lane == root_slot) ? root_scale * rp[i] : (hp[i] - rp[i]) * s_scale + root_scale * rp[i];
+        qnormalize(hq);
         qmul(hq, s_roff, qo);
-        qnormalize(qo);
+        qrenorm(qo);
         q2mat(qo, R);
         mv(R, s_poff, g);
 #pragma unroll
         for (int i = 0; i < 3; i++) p[i] += g[i];
-        if (s_foot) pz = p[2];
+        if (m.sfoot[lane]) pz = p[2];
       }
       if (prm.offset_to_ground) {
         const double lowest = wave_min(pz);
@@ -546,31 +670,33 @@ __global__ void __launch_bounds__(64, 2) ik_kernel(DevModel m, IkLaunch L, LdsLa
       }
     }
     __syncthreads();
+    GMR_STAMP(0);
 
     int solves = 0, qpflag = 0;
     for (int tab = 0; tab < 2; ++tab) {
       if (!m.use_table[tab]) continue;
       const int nt = m.ntask[tab];
       const bool is_task = lane < nt;
-      int t_body = 0, t_slot = 0;
-      double t_wp = 0, t_wr = 0;
-      if (is_task) {
-        t_body = m.tbody[tab * GMR_MAX_TASKS + lane]; t_slot = m.tslot[tab * GMR_MAX_TASKS + lane];
-        t_wp = m.twp[tab * GMR_MAX_TASKS + lane]; t_wr = m.twr[tab * GMR_MAX_TASKS + lane];
-      }
-      const int a_comp = real_row ? m.acomp[tab * 64 + lane] : 0;
+      const int trow = tab * GMR_MAX_TASKS + (is_task ? lane : 0);
+      const int t_body = m.tbody[trow], t_slot = m.tslot[trow];
+      const double t_wp = m.twp[trow], t_wr = m.twr[trow];
+      const int a_comp = m.acomp[tab * 64 + arow];
       const int ncomp = m.ncomp[tab];
+      const unsigned *cmask = m.compmask + tab * 2 * GMR_MAX_TASKS;
 
-      double e[6] = {0, 0, 0, 0, 0, 0};
-      fk_phase(m, bc, lane, q, xpos, xquat);
-      double curr = sqrt(wave_sum(is_task ? task_residual(t_body, t_slot, xpos, xquat, tp, tq, e) : 0.0));
+      double e[6] = {0, 0, 0, 0, 0, 0}, sh = 0.0, ch = 1.0;
+      fk_phase(bodyc, nbody, fkrounds, lane, q, xpos, xquat);
+      GMR_STAMP(1);
+      double curr = fast_sqrt(wave_sum(is_task ? task_residual(t_body, t_slot, xpos, xquat, tp, tq, e, sh, ch) : 0.0));
+      GMR_STAMP(2);
       int num_iter = 0;
       bool first = true;
       for (;;) {
         // ---- per-task 6x6 blocks ----
         double mu = 0.0;
-        if (is_task) mu = task_block(t_body, xpos, xquat, e, t_wp, t_wr, Bt + kBT * lane);
+        if (is_task) mu = task_block(t_body, xpos, xquat, e, sh, ch, t_wp, t_wr, Bt + kBT * lane);
         const double diag = prm.damping + prm.lm_damping * wave_sum(mu);
+        GMR_STAMP(3);
         // ---- screws S_i (world frame, about the origin) ----
         double Si[6] = {0, 0, 0, 0, 0, 0};
         if (real_row) {
@@ -579,6 +705,8 @@ __global__ void __launch_bounds__(64, 2) ik_kernel(DevModel m, IkLaunch L, LdsLa
           } else {
             const double qb[4] = {xquat[4 * a_body], xquat[4 * a_body + 1], xquat[4 * a_body + 2], xquat[4 * a_body + 3]};
             const double xb[3] = {xpos[3 * a_body], xpos[3 * a_body + 1], xpos[3 * a_body + 2]};
+            const int ab = launder(a_body);
+            const double a_axis[3] = {m.axis[3 * ab], m.axis[3 * ab + 1], m.axis[3 * ab + 2]};
             double R[9], ax[3], mo[3];
             q2mat(qb, R);
             if (a_kind < 6) { ax[0] = R[a_kind - 3]; ax[1] = R[a_kind]; ax[2] = R[a_kind + 3]; }  // root-body-frame axes
@@ -590,45 +718,71 @@ __global__ void __launch_bounds__(64, 2) ik_kernel(DevModel m, IkLaunch L, LdsLa
           for (int k = 0; k < 6; k++) S[6 * lane + k] = Si[k];
         }
         __syncthreads();
+        GMR_STAMP(4);
         // ---- composites: Bc[c] = sum of task blocks below the joint ----
-        for (int idx = lane; idx < ncomp * kBT; idx += 64) {
-          const int c = idx / kBT, el = idx - c * kBT;
-          double s = 0.0;
-          for (unsigned mm = m.compmask[tab * 2 * GMR_MAX_TASKS + c]; mm; mm &= mm - 1) s += Bt[kBT * __builtin_ctz(mm) + el];
-          Bc[idx] = s;
+        {
+          const int half = lane >> 5, el = lane & 31;  // two composite nodes per pass: lanes 0-26 and 32-58
+          for (int c0 = 0; c0 < ncomp; c0 += 2) {
+            const int c = c0 + half;
+            const unsigned m0 = cmask[c0], m1 = c0 + 1 < ncomp ? cmask[c0 + 1] : 0u;  // wave-uniform (scalar loads)
+            const unsigned mine = half ? m1 : m0;
+            double s = 0.0;
+            const int ec = el < kBT ? el : 0;
+            for (int t0 = 0; t0 < nt; t0 += 16) {  // 16 independent LDS reads in flight, then the masked adds
+              double v[16];
+#pragma unroll
+              for (int t = 0; t < 16; t++) v[t] = Bt[kBT * min(t0 + t, nt - 1) + ec];
+#pragma unroll
+              for (int t = 0; t < 16; t++) s = fma(v[t], (t0 + t < nt) && ((mine >> (t0 + t)) & 1u) ? 1.0 : 0.0, s);
+            }
+            if (el < kBT && c < ncomp) Bc[kBT * c + el] = s;
+          }
         }
         __syncthreads();
-        double Fi[6] = {0, 0, 0, 0, 0, 0}, ci = 0.0, lo = -1e30, hi = 1e30;
+        GMR_STAMP(5);
+        double ci = 0.0, lo = -1e30, hi = 1e30;
         if (real_row) {
           const double *B = Bc + kBT * a_comp;
+          double Fi[6];
           sym6_mul(B, Si, Si + 3, Fi, Fi + 3);
+#pragma unroll
+          for (int k = 0; k < 6; k++) F[6 * lane + k] = Fi[k];
           ci = Si[0] * B[21] + Si[1] * B[22] + Si[2] * B[23] + Si[3] * B[24] + Si[4] * B[25] + Si[5] * B[26];
           if (a_lim) {  // mink ConfigurationLimit: -gain (q - lower) <= dq <= gain (upper - q)
             const double qv = q[a_qadr];
-            lo = -prm.limit_gain * (qv - a_rlo);
-            hi = prm.limit_gain * (a_rhi - qv);
+            const int ar = launder(2 * lane);
+            lo = -prm.limit_gain * (qv - m.arange[ar]);
+            hi = prm.limit_gain * (m.arange[ar + 1] - qv);
           }
         }
         __syncthreads();  // Bc / poses are dead from here: H overwrites them
+        GMR_STAMP(6);
+        // ---- H (dense, symmetric) into LDS: zero fill, then the structurally non-zero pairs spread over all lanes ----
         for (int idx = lane; idx < NVP * NVP; idx += 64) Hm[idx] = 0.0;
         __syncthreads();
-        if (real_row) {  // H[i][j] = S_j . F_i for every dof j above i (and the mirror), H[i][i] = S_i . F_i + diag
-          for (u64 mm = a_anc; mm; mm &= mm - 1) {
-            const int j = (int)__builtin_ctzll(mm);
-            const double *Sj = S + 6 * j;
+#pragma unroll
+        for (int r = 0; r < kPairRounds; r++) {  // H[i][j] = S_j . F_i for every dof j above i (and the mirror)
+          if (64 * r >= npair) break;  // wave-uniform
+          const int pi = launder(lane + 64 * r);
+          const int pr = pi < npair ? (int)pairs[pi] : -1;
+          if (pr >= 0) {
+            const int i = pr >> 8, j = pr & 0xff;
+            const double *Sj = S + 6 * j, *Fi = F + 6 * i;
             const double d = Sj[0] * Fi[0] + Sj[1] * Fi[1] + Sj[2] * Fi[2] + Sj[3] * Fi[3] + Sj[4] * Fi[4] + Sj[5] * Fi[5];
-            Hm[j * NVP + lane] = d;
-            Hm[lane * NVP + j] = d;
+            Hm[j * NVP + i] = d;
+            Hm[i * NVP + j] = d;
           }
-          Hm[lane * NVP + lane] =
-              Si[0] * Fi[0] + Si[1] * Fi[1] + Si[2] * Fi[2] + Si[3] * Fi[3] + Si[4] * Fi[4] + Si[5] * Fi[5] + diag;
-        } else if (lane < NVP) {
-          Hm[lane * NVP + lane] = 1.0;
+        }
+        if (lane < NVP) {
+          const double *Fi = F + 6 * lane;
+          Hm[lane * NVP + lane] = real_row ? Si[0] * Fi[0] + Si[1] * Fi[1] + Si[2] * Fi[2] + Si[3] * Fi[3] + Si[4] * Fi[4] + Si[5] * Fi[5] + diag : 1.0;
         }
         __syncthreads();
+        GMR_STAMP(7);
         double dq;
-        const int qit = box_qp<NVP>(lane, m.n_act, Hm, ci, lo, hi, status, dq);
+        const int qit = box_qp<NVP>(lane, n_act, Hm, lds + lay.Lb, ci, lo, hi, status, dq);
         if (qit < 0) qpflag = 1;
+        GMR_STAMP(8);
         // ---- integrate (mj_integratePos) ----
         {
           const double wx = rdlane(dq, 3), wy = rdlane(dq, 4), wz = rdlane(dq, 5);
@@ -637,23 +791,27 @@ __global__ void __launch_bounds__(64, 2) ik_kernel(DevModel m, IkLaunch L, LdsLa
             else if (a_kind == 6) q[a_qadr] += dq;
           }
           if (lane == 0) {
-            const double ang = sqrt(wx * wx + wy * wy + wz * wz);
-            if (ang > 0) {
+            const double a2 = wx * wx + wy * wy + wz * wz;
+            if (a2 > 0) {
+              const double ang = fast_sqrt(a2);
               double s, c;
-              sincos(0.5 * ang, &s, &c);
-              s /= ang;
+              sincos_small(0.5 * ang, &s, &c);
+              s *= fast_rcp(ang);
               const double dqt[4] = {c, s * wx, s * wy, s * wz}, q0[4] = {q[3], q[4], q[5], q[6]};
               double o[4];
               qmul(q0, dqt, o);
-              const double n = 1.0 / sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
-              q[3] = o[0] * n; q[4] = o[1] * n; q[5] = o[2] * n; q[6] = o[3] * n;
+              qnormalize(o);
+              q[3] = o[0]; q[4] = o[1]; q[5] = o[2]; q[6] = o[3];
             }
           }
         }
         __syncthreads();
+        GMR_STAMP(9);
         ++solves;
-        fk_phase(m, bc, lane, q, xpos, xquat);
-        const double next = sqrt(wave_sum(is_task ? task_residual(t_body, t_slot, xpos, xquat, tp, tq, e) : 0.0));
+        fk_phase(bodyc, nbody, fkrounds, lane, q, xpos, xquat);
+        GMR_STAMP(1);
+        const double next = fast_sqrt(wave_sum(is_task ? task_residual(t_body, t_slot, xpos, xquat, tp, tq, e, sh, ch) : 0.0));
+        GMR_STAMP(2);
         if (!first) ++num_iter;
         first = false;
         if (!(curr - next > prm.tol && num_iter < prm.max_iter)) break;
@@ -661,13 +819,17 @@ __global__ void __launch_bounds__(64, 2) ik_kernel(DevModel m, IkLaunch L, LdsLa
       }
     }
     if (kf >= w.n_burn) {
-      for (int i = lane; i < m.nq; i += 64) L.qout[(size_t)f * m.nq + i] = q[i];
+      for (int i = lane; i < nq; i += 64) L.qout[(size_t)f * nq + i] = q[i];
       if (L.iters && lane == 0) L.iters[f] = solves | (qpflag << 30);
     }
     __syncthreads();
   }
   if (w.final_row >= 0 && L.qfinal)
-    for (int i = lane; i < m.nq; i += 64) L.qfinal[(size_t)w.final_row * m.nq + i] = q[i];
+    for (int i = lane; i < nq; i += 64) L.qfinal[(size_t)w.final_row * nq + i] = q[i];
+#ifdef GMR_IK_STAMPS
+  if (lane == 0 && L.dbg)
+    for (int i = 0; i < 16; i++) atomicAdd(L.dbg + i, stamp_acc[i]);
+#endif
 }
 
 }  // namespace gmr
