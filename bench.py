@@ -63,6 +63,23 @@ def flops_per_solve(cm) -> float:
     return float(np.mean(out))
 
 
+def host_cores() -> int:
+    """CPU threads this process may actually use: cgroup quota, then affinity, then os.cpu_count()."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+# HBM bytes per output frame of ik_kernel measured with rocprofv3 PMC passes (profiles/r01_v2_pmc_*: 2 x FETCH_SIZE
+# (gfx950 counts half, MI355X_MICROARCH.md "HBM") + WRITE_SIZE over a 1.2288e6-frame launch): 486 + 364 MB.
+MEASURED_TRAFFIC_BYTES_PER_FRAME = (2 * 237367.0 * 1024 + 355521.0 * 1024) / 1228800.0
+
+
 def bytes_per_frame(cm, in_itemsize=4) -> int:
     """Compulsory HBM traffic of the IK kernel per output frame: key-points in, qpos (f64) + solve count out."""
     return cm.nslot * 7 * in_itemsize + cm.robot.nq * 8 + 4
@@ -160,7 +177,7 @@ def main():
                 "clips_per_gpu": S, "frames_per_clip": T, "frames_per_step": n_frames * world, "parallelism": f"clip-sharded x{world}",
             },
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "gmr::ik_kernel<36>", "kernel_ms": kern_ms, "bytes_per_frame": bpf},
+                         "traffic": MEASURED_TRAFFIC_BYTES_PER_FRAME * n_frames, "traffic_source": "profiles/r01_v2_pmc_* scaled to this launch", "kernel": "gmr::ik_kernel<36>", "kernel_ms": kern_ms, "bytes_per_frame": bpf},
             "valu": {"bound": "fp64-vector", "achieved": ach_tf, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": ach_tf / FP64_VECTOR_PEAK_TF,
                      "flop_per_solve": fsolve, "mean_solves_per_frame": mean_solves},
             "qp_iteration_caps_hit": qp_capped,
@@ -168,8 +185,8 @@ def main():
         if world == 1 and not args.no_cpu:
             from oracle.oracle import Oracle  # checker / comparator only
             orc = Oracle(cm.blob)
-            cores = os.cpu_count() or 1
-            nc = min(args.cpu_clips if args.cpu_clips > 0 else min(512, 2 * cores), S)
+            cores = host_cores()
+            nc = min(args.cpu_clips if args.cpu_clips > 0 else min(512, max(32, 4 * cores)), S)
             cp, cq = pos[: nc * T].cpu().numpy(), quat[: nc * T].cpu().numpy()
             citems = make_items(offs[: nc + 1])
             one = 4

@@ -165,17 +165,57 @@ int build_device_model(gmr_model *m) {
   const int n_act = (int)abody.size();
   const int nvp = pick_nvp(n_act);
   if (nvp < 0) { set_err(m, "%d active dofs exceed the kernel limit of 64", n_act); return GMR_EUNSUPPORTED; }
-  std::vector<u64> aanc(64, 0);
-  for (int i = 0; i < n_act; ++i) {
-    u64 mk = 0;
-    for (int j = 0; j < i; ++j) {
-      bool anc;
-      if (akind[i] < 6) anc = true;                 // root dofs form a chain 0 <- 1 <- ... <- 5
-      else if (akind[j] < 6) anc = true;            // every hinge hangs below the root's six dofs
-      else anc = abody[j] != abody[i] && above(abody[j], abody[i]);
-      if (anc) mk |= 1ull << j;
+  // ancestor relation among active dofs in depth-first order (j above i implies j < i)
+  auto dfs_anc = [&](int j, int i) {
+    if (j >= i) return false;
+    if (akind[i] < 6) return true;       // root dofs form a chain 0 <- 1 <- ... <- 5
+    if (akind[j] < 6) return true;       // every hinge hangs below the root's six dofs
+    return abody[j] != abody[i] && above(abody[j], abody[i]);
+  };
+  // ---- elimination order of the QP: sort dofs by height (longest chain of dofs below), tallest first.  Dofs of equal
+  //      height are never above one another, so a kinematic tree eliminates leaves-first without fill-in and all dofs of
+  //      one height can be eliminated in the same step (level-scheduled sparse U D U' in ik_kernel's box_qp). ----
+  std::vector<int> height(n_act, 0), perm(n_act);
+  for (int i = n_act - 1; i >= 0; --i)
+    for (int j = 0; j < i; ++j)
+      if (dfs_anc(j, i)) height[j] = std::max(height[j], height[i] + 1);
+  std::vector<u64> anc_dfs(n_act, 0);  // relation in depth-first indices, taken before the arrays are permuted
+  for (int i = 0; i < n_act; ++i)
+    for (int j = 0; j < i; ++j)
+      if (dfs_anc(j, i)) anc_dfs[i] |= 1ull << j;
+  std::iota(perm.begin(), perm.end(), 0);
+  std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return height[a] > height[b]; });
+  for (int k = 0; k < 6; ++k)
+    if (perm[k] != k) { set_err(m, "internal: root dofs must lead the elimination order"); return GMR_EINVAL; }
+  {
+    std::vector<int> b2(n_act), k2(n_act), q2(n_act), l2(n_act), h2(n_act);
+    std::vector<double> r2(2 * n_act);
+    for (int a = 0; a < n_act; ++a) {
+      const int o = perm[a];
+      b2[a] = abody[o]; k2[a] = akind[o]; q2[a] = aqadr[o]; l2[a] = alim[o]; h2[a] = height[o];
+      r2[2 * a] = arange[2 * o]; r2[2 * a + 1] = arange[2 * o + 1];
     }
-    aanc[i] = mk;
+    abody = b2; akind = k2; aqadr = q2; alim = l2; arange = r2; height = h2;
+  }
+  std::vector<u64> aanc(64, 0);
+  for (int a = 0; a < n_act; ++a)
+    for (int b = 0; b < n_act; ++b)
+      if ((anc_dfs[perm[a]] >> perm[b]) & 1ull) {
+        if (b >= a) { set_err(m, "internal: elimination order breaks ancestor-first indexing"); return GMR_EINVAL; }
+        aanc[a] |= 1ull << b;
+      }
+  // batches of mutually independent pivots (<= 4 consecutive indices of one height; padding rows are independent of
+  // everything): bit p of qp_top marks the highest index of a batch.
+  u64 qp_top = 0;
+  {
+    auto group = [&](int p) { return p >= n_act ? -1 : height[p]; };
+    int p = nvp - 1;
+    while (p >= 0) {
+      qp_top |= 1ull << p;
+      int w = 1;
+      while (w < 4 && p - w >= 0 && group(p - w) == group(p)) ++w;
+      p -= w;
+    }
   }
   // ---- FK pointer-jumping plan: ancestor folded in each round, one byte per round ----
   int fkrounds = 0;
@@ -202,7 +242,7 @@ int build_device_model(gmr_model *m) {
       if ((aanc[i] >> j) & 1ull) hpair.push_back((unsigned short)((i << 8) | j));
   // ---- composites per table: dofs sharing the same set of tasks below them share one 6x6 block ----
   std::vector<int> acomp(2 * 64, 0);
-  std::vector<unsigned> compmask(2 * 2 * GMR_MAX_TASKS, 0u);
+  std::vector<unsigned> compmask(2 * 2 * GMR_MAX_TASKS, 0u), comp_own(64, 0u), comp_kids(64, 0u);
   int ncomp[2] = {0, 0};
   for (int k = 0; k < 2; ++k) {
     std::map<unsigned, int> ids;
@@ -219,6 +259,29 @@ int build_device_model(gmr_model *m) {
       acomp[k * 64 + i] = it->second;
     }
     if (ncomp[k] > 2 * GMR_MAX_TASKS) { set_err(m, "too many composite nodes"); return GMR_EUNSUPPORTED; }
+    // renumber the composites so that a composite's children (maximal strict subsets) always have lower ids, and split
+    // each into "own tasks" + "child composites": Bc[c] = sum_{t in own} Bt[t] + sum_{d in kids} Bc[d]
+    const int nc = ncomp[k];
+    if (nc > 32) { set_err(m, "more than 32 composite nodes"); return GMR_EUNSUPPORTED; }
+    std::vector<int> order(nc), newid(nc);
+    std::iota(order.begin(), order.end(), 0);
+    auto mask_of = [&](int c) { return compmask[k * 2 * GMR_MAX_TASKS + c]; };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return __builtin_popcount(mask_of(a)) < __builtin_popcount(mask_of(b)); });
+    std::vector<unsigned> sorted_mask(nc);
+    for (int o = 0; o < nc; ++o) { newid[order[o]] = o; sorted_mask[o] = mask_of(order[o]); }
+    for (int i = 0; i < n_act; ++i) acomp[k * 64 + i] = newid[acomp[k * 64 + i]];
+    for (int o = 0; o < nc; ++o) {
+      compmask[k * 2 * GMR_MAX_TASKS + o] = sorted_mask[o];
+      unsigned own = sorted_mask[o], kids = 0, covered = 0;
+      for (int d = o - 1; d >= 0; --d) {
+        const unsigned md = sorted_mask[d];
+        if (md == 0 || md == sorted_mask[o] || (md & ~sorted_mask[o]) != 0 || (md & covered) != 0) continue;
+        kids |= 1u << d; covered |= md;
+      }
+      own &= ~covered;
+      if (__builtin_popcount(own) > 4 || __builtin_popcount(kids) > 4) { set_err(m, "composite %d of table %d: more than 4 own tasks / children", o, k + 1); return GMR_EUNSUPPORTED; }
+      comp_own[k * 32 + o] = own; comp_kids[k * 32 + o] = kids;
+    }
   }
   // ---- FK (KinematicsModel convention) tables and branch-slot plan ----
   std::vector<int> dofidx(nb, -1), src_slot(nb, -1), save_slot(nb, -1), last_child(nb, -1), nchild_other(nb, 0);
@@ -263,7 +326,7 @@ int build_device_model(gmr_model *m) {
   const size_t o_tbody = P.add(tbody), o_tslot = P.add(tslot), o_twp = P.add(twp), o_twr = P.add(twr);
   const size_t o_abody = P.add(abody), o_akind = P.add(akind), o_aqadr = P.add(aqadr), o_alim = P.add(alim);
   const size_t o_aanc = P.add(aanc), o_arange = P.add(arange), o_acomp = P.add(acomp), o_compmask = P.add(compmask);
-  const size_t o_hpair = P.add(hpair), o_fkanc = P.add(fkanc);
+  const size_t o_hpair = P.add(hpair), o_fkanc = P.add(fkanc), o_cown = P.add(comp_own), o_ckids = P.add(comp_kids);
   const size_t o_dm = P.add(std::vector<gmr::DevModel>(1));
   const size_t o_dofidx = P.add(dofidx), o_src = P.add(src_slot), o_save = P.add(save_slot);
   const size_t o_lpos = P.add(lpos), o_lrot = P.add(lrot), o_jaxis = P.add(jaxis), o_jaxis64 = P.add(jaxis64);
@@ -281,7 +344,7 @@ int build_device_model(gmr_model *m) {
   dm.tbody = DP(int, o_tbody); dm.tslot = DP(int, o_tslot); dm.twp = DP(double, o_twp); dm.twr = DP(double, o_twr);
   dm.abody = DP(int, o_abody); dm.akind = DP(int, o_akind); dm.aqadr = DP(int, o_aqadr); dm.alimited = DP(int, o_alim);
   dm.aanc = DP(u64, o_aanc); dm.arange = DP(double, o_arange); dm.acomp = DP(int, o_acomp); dm.compmask = DP(unsigned, o_compmask);
-  dm.hpair = DP(unsigned short, o_hpair); dm.npair = (int)hpair.size(); dm.fkanc = DP(u64, o_fkanc); dm.fkrounds = fkrounds;
+  dm.hpair = DP(unsigned short, o_hpair); dm.comp_own = DP(unsigned, o_cown); dm.comp_kids = DP(unsigned, o_ckids); dm.npair = (int)hpair.size(); dm.fkanc = DP(u64, o_fkanc); dm.fkrounds = fkrounds;
   m->dm_dev = DP(gmr::DevModel, o_dm);
   gmr::FkTree &fk = m->fk;
   fk.parent = DP(int, o_parent); fk.dofidx = DP(int, o_dofidx); fk.src_slot = DP(int, o_src); fk.save_slot = DP(int, o_save);
@@ -301,8 +364,8 @@ int build_device_model(gmr_model *m) {
   L.tq = o; o += 4 * ns;
   L.S = o; o += 6 * nvp;
   L.F = o; o += 6 * nvp;
-  L.Lb = o; o += 128;  // two 64-entry broadcast rows of the Cholesky
-  L.bodyc = o; o += gmr::kBodyC * nb;
+  L.Lb = o; o += 2 * (nvp + 2);  // two broadcast rows of the Cholesky (+ a dummy slot for lanes beyond the matrix)
+  L.bodyc = o; o += gmr::kBodyC * nb + ((gmr::kBodyC * nb) & 1);
   L.pairs = o; o += ((int)hpair.size() + 3) / 4 + (((int)hpair.size() + 3) / 4 & 1);
   L.xpos = o; L.H = o;
   int r = o;
@@ -310,7 +373,7 @@ int build_device_model(gmr_model *m) {
   L.xquat = r; r += 4 * nb;
   L.B = r; r += gmr::kBT * ntmax + ((gmr::kBT * ntmax) & 1);
   L.Bc = r; r += gmr::kBT * ncmax + ((gmr::kBT * ncmax) & 1);
-  o = std::max(r, o + nvp * nvp);
+  o = std::max(r, o + nvp * nvp + 2);  // + a dummy slot for the unused lanes of the pair rounds
   L.total_doubles = o;
   m->lds_bytes = o * (int)sizeof(double);
   m->nvp = nvp;

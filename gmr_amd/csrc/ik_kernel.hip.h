@@ -78,6 +78,7 @@ struct DevModel {
   const unsigned *compmask;                     // [2][GMR_MAX_TASKS*2] tasks summed into each composite
   const unsigned short *hpair;                  // [npair] (i << 8) | j for every dof j strictly above dof i
   const u64 *fkanc;                             // [nbody] byte r = ancestor folded in FK round r (0xff: none)
+  const unsigned *comp_own, *comp_kids;         // [2][32] per composite: its own tasks / its child composites (lower ids)
   int npair, fkrounds;
 };
 
@@ -253,14 +254,14 @@ __device__ __forceinline__ void qrot(const double q[4], const double v[3], doubl
   o[1] = v[1] + q[0] * ty + (q[3] * tx - q[1] * tz);
   o[2] = v[2] + q[0] * tz + (q[1] * ty - q[2] * tx);
 }
-constexpr int kBodyC = 12;  // doubles per body in the LDS-staged joint tree: pos(3) quat(4) axis(3) {jtype,qadr} fkanc
+constexpr int kBodyC = 11;  // doubles per body in the LDS-staged joint tree: pos(3) quat(4) axis(3) {fkanc(6 bytes), jtype, qadr}
 __device__ __forceinline__ void fk_phase(const double *bodyc, int nbody, int nrounds, int lane, const double *q, double *xpos,
                                          double *xquat) {
   const bool has = lane < nbody;
   const double *bcst = bodyc + kBodyC * (has ? lane : 0);
-  const long long packed = __double_as_longlong(bcst[10]);
-  const int jtype = (int)(packed & 0xff), qadr = (int)(packed >> 8);
-  const u64 ancs = has ? (u64)__double_as_longlong(bcst[11]) : ~0ull;
+  const u64 packed = (u64)__double_as_longlong(bcst[10]);
+  const int jtype = (int)((packed >> 48) & 0xff), qadr = (int)(packed >> 56);
+  const u64 ancs = has ? (packed | 0xffff000000000000ull) : ~0ull;
   double pos[3] = {bcst[0], bcst[1], bcst[2]};
   const double bq[4] = {bcst[3], bcst[4], bcst[5], bcst[6]};
   const double ax[3] = {bcst[7], bcst[8], bcst[9]};
@@ -447,7 +448,8 @@ __device__ __forceinline__ int box_qp(int lane, int n_act, const double *Hm, dou
                                       double &x_out) {
   const bool real_row = lane < n_act;
   const int li = lane < NVP ? lane : 0;  // lanes beyond the matrix shadow row 0: they only ever receive broadcasts
-  double *Yb = Lb + 64;
+  const int lw = lane < NVP ? lane : NVP;  // ... and write their (unused) column entries to a dummy slot
+  double *Yb = Lb + NVP + 2;
   const u64 real_mask = n_act >= 64 ? ~0ull : ((1ull << n_act) - 1ull);
   double x = 0.0;
   if (real_row) {
@@ -474,10 +476,13 @@ __device__ __forceinline__ int box_qp(int lane, int n_act, const double *Hm, dou
     // this lane's row of H, rows/columns of the working set replaced by the identity (straight-line: selects only)
     double R[NVP];
 #pragma unroll
-    for (int j = 0; j < NVP; j++) {
-      const double h = Hm[j * NVP + li];
-      const bool fj = (fixed >> j) & 1ull;
-      R[j] = (fj || mine_fixed) ? (j == lane ? 1.0 : 0.0) : h;
+    for (int j = 0; j < NVP; j++) R[j] = Hm[j * NVP + li];  // padding rows are already identity in LDS
+    if (fixed_real) {  // wave-uniform: only then rows/columns of the working set have to become the identity
+#pragma unroll
+      for (int j = 0; j < NVP; j++) {
+        const bool fj = (fixed >> j) & 1ull;
+        R[j] = (fj || mine_fixed) ? (j == lane ? 1.0 : 0.0) : R[j];
+      }
     }
     double myinv = 1.0;
 #if GMR_QP_LDS_BCAST
@@ -493,8 +498,8 @@ __device__ __forceinline__ int box_qp(int lane, int n_act, const double *Hm, dou
       const double lk = R[k] * inv;
       const double l = lane == k ? dkk * inv - 1.0 : (lane < k ? 0.0 : lk);
       myinv = lane == k ? inv : myinv;
-      Lb[lane] = l;
-      Yb[lane] = b * inv;
+      Lb[lw] = l;
+      Yb[lw] = b * inv;
       __syncthreads();
       const double yk = Yb[k];
 #pragma unroll
@@ -603,8 +608,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
     for (int i = 0; i < 3; i++) { bcst[i] = m.bpos[3 * lane + i]; bcst[7 + i] = m.axis[3 * lane + i]; }
 #pragma unroll
     for (int i = 0; i < 4; i++) bcst[3 + i] = m.bquat[4 * lane + i];
-    bcst[10] = __longlong_as_double((long long)m.jtype[lane] | ((long long)m.qadr[lane] << 8));
-    bcst[11] = __longlong_as_double((long long)m.fkanc[lane]);
+    bcst[10] = __longlong_as_double((long long)((m.fkanc[lane] & 0x0000ffffffffffffull) | ((u64)(m.jtype[lane] & 0xff) << 48) | ((u64)(m.qadr[lane] & 0xff) << 56)));
   }
   for (int i = lane; i < npair; i += 64) pairs[i] = m.hpair[i];
   for (int i = lane; i < nq; i += 64) q[i] = w.init_row >= 0 ? L.qinit[(size_t)w.init_row * nq + i] : m.qpos0[i];
@@ -682,7 +686,6 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
       const double t_wp = m.twp[trow], t_wr = m.twr[trow];
       const int a_comp = m.acomp[tab * 64 + arow];
       const int ncomp = m.ncomp[tab];
-      const unsigned *cmask = m.compmask + tab * 2 * GMR_MAX_TASKS;
 
       double e[6] = {0, 0, 0, 0, 0, 0}, sh = 0.0, ch = 1.0;
       fk_phase(bodyc, nbody, fkrounds, lane, q, xpos, xquat);
@@ -720,22 +723,30 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         __syncthreads();
         GMR_STAMP(4);
         // ---- composites: Bc[c] = sum of task blocks below the joint ----
-        {
-          const int half = lane >> 5, el = lane & 31;  // two composite nodes per pass: lanes 0-26 and 32-58
-          for (int c0 = 0; c0 < ncomp; c0 += 2) {
-            const int c = c0 + half;
-            const unsigned m0 = cmask[c0], m1 = c0 + 1 < ncomp ? cmask[c0 + 1] : 0u;  // wave-uniform (scalar loads)
-            const unsigned mine = half ? m1 : m0;
-            double s = 0.0;
-            const int ec = el < kBT ? el : 0;
-            for (int t0 = 0; t0 < nt; t0 += 16) {  // 16 independent LDS reads in flight, then the masked adds
-              double v[16];
+        {  // lane = block element (27 lanes).  Composites are numbered children-first, so one pass in id order builds each
+           // from <= 4 own task blocks + <= 4 child composites; the plan is wave-uniform (scalar loads), and the <= 8 LDS
+           // reads of a composite are issued together.
+          const int ec = lane < kBT ? lane : 0;
+          const unsigned *cown = m.comp_own + 32 * tab, *ckids = m.comp_kids + 32 * tab;
+          for (int c = 0; c < ncomp; ++c) {
+            unsigned own = cown[c], kids = ckids[c];
+            double v[8];
 #pragma unroll
-              for (int t = 0; t < 16; t++) v[t] = Bt[kBT * min(t0 + t, nt - 1) + ec];
-#pragma unroll
-              for (int t = 0; t < 16; t++) s = fma(v[t], (t0 + t < nt) && ((mine >> (t0 + t)) & 1u) ? 1.0 : 0.0, s);
+            for (int k = 0; k < 4; k++) {
+              const bool on = own != 0;
+              const int t = on ? __builtin_ctz(own) : 0;
+              own &= own - 1;
+              v[k] = on ? Bt[kBT * t + ec] : 0.0;
             }
-            if (el < kBT && c < ncomp) Bc[kBT * c + el] = s;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              const bool on = kids != 0;
+              const int d = on ? __builtin_ctz(kids) : 0;
+              kids &= kids - 1;
+              v[4 + k] = on ? Bc[kBT * d + ec] : 0.0;
+            }
+            const double s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            if (lane < kBT) Bc[kBT * c + lane] = s;
           }
         }
         __syncthreads();
@@ -758,19 +769,20 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         __syncthreads();  // Bc / poses are dead from here: H overwrites them
         GMR_STAMP(6);
         // ---- H (dense, symmetric) into LDS: zero fill, then the structurally non-zero pairs spread over all lanes ----
-        for (int idx = lane; idx < NVP * NVP; idx += 64) Hm[idx] = 0.0;
-        __syncthreads();
+        for (int idx = lane; idx < NVP * NVP; idx += 64) Hm[idx] = 0.0;  // same wave: LDS keeps program order, no barrier needed
+        {
+          int prs[kPairRounds];
 #pragma unroll
-        for (int r = 0; r < kPairRounds; r++) {  // H[i][j] = S_j . F_i for every dof j above i (and the mirror)
-          if (64 * r >= npair) break;  // wave-uniform
-          const int pi = launder(lane + 64 * r);
-          const int pr = pi < npair ? (int)pairs[pi] : -1;
-          if (pr >= 0) {
-            const int i = pr >> 8, j = pr & 0xff;
-            const double *Sj = S + 6 * j, *Fi = F + 6 * i;
-            const double d = Sj[0] * Fi[0] + Sj[1] * Fi[1] + Sj[2] * Fi[2] + Sj[3] * Fi[3] + Sj[4] * Fi[4] + Sj[5] * Fi[5];
-            Hm[j * NVP + i] = d;
-            Hm[i * NVP + j] = d;
+          for (int r = 0; r < kPairRounds; r++) prs[r] = lane + 64 * r < npair ? (int)pairs[launder(lane + 64 * r)] : -1;
+#pragma unroll
+          for (int r = 0; r < kPairRounds; r++) {  // H[i][j] = S_j . F_i for every dof j above i (and the mirror)
+            if (64 * r < npair) {  // wave-uniform
+              const int pr = prs[r], i = pr >= 0 ? pr >> 8 : 0, j = pr >= 0 ? pr & 0xff : 0;
+              const double *Sj = S + 6 * j, *Fi = F + 6 * i;
+              const double d = Sj[0] * Fi[0] + Sj[1] * Fi[1] + Sj[2] * Fi[2] + Sj[3] * Fi[3] + Sj[4] * Fi[4] + Sj[5] * Fi[5];
+              Hm[pr >= 0 ? j * NVP + i : NVP * NVP] = d;       // unused lanes hit the dummy slot
+              Hm[pr >= 0 ? i * NVP + j : NVP * NVP + 1] = d;
+            }
           }
         }
         if (lane < NVP) {
@@ -783,6 +795,9 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         const int qit = box_qp<NVP>(lane, n_act, Hm, lds + lay.Lb, ci, lo, hi, status, dq);
         if (qit < 0) qpflag = 1;
         GMR_STAMP(8);
+#ifdef GMR_IK_STAMPS
+        stamp_acc[15] += (u64)(qit < 0 ? -qit : qit);  // QP iterations (not cycles)
+#endif
         // ---- integrate (mj_integratePos) ----
         {
           const double wx = rdlane(dq, 3), wy = rdlane(dq, 4), wz = rdlane(dq, 5);

@@ -34,6 +34,7 @@ eng._lib.gmr_debug_read_stamps(eng._h, out)
 v = np.array(list(out), dtype=np.float64)
 names_ = ["prep", "fk", "residual", "task_block", "screws", "composites", "F_c_limits", "H_assemble", "box_qp", "integrate", "output"]
 solves = float((it & 0x3FFFFFFF).sum().item())
-print(f"total solves {solves:.0f}; cycles per solve per wave: {v.sum() / solves:.0f}")
+qp_iters = v[15]; v[15] = 0
+print(f"total solves {solves:.0f}; QP iterations per solve {qp_iters / solves:.3f}; cycles per solve per wave: {v.sum() / solves:.0f}")
 for n, x in zip(names_, v):
     print(f"  {n:12s} {100 * x / v.sum():6.2f} %   {x / solves:9.0f} cyc/solve")
