@@ -182,6 +182,26 @@ def main():
                      "flop_per_solve": fsolve, "mean_solves_per_frame": mean_solves},
             "qp_iteration_caps_hit": qp_capped,
         }
+        if world == 1:
+            # BASELINE config 2 taken literally: ONE 3000-frame clip on one GPU, parallel-in-time chunks with verified
+            # boundaries (Engine.ik_solve_chunked) vs the same clip solved sequentially by one wavefront.
+            one_p, one_q, one_offs = pos[:T].contiguous(), quat[:T].contiguous(), offs[:2]
+            def timed(fn, reps=5):
+                ts = []
+                for _ in range(reps):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    r = fn()
+                    torch.cuda.synchronize()
+                    ts.append(time.perf_counter() - t1)
+                return float(np.median(ts)), r
+            t_seq, (q_seq, _, _) = timed(lambda: eng.ik_solve(one_p, one_q, sc, make_items(one_offs)), reps=3)
+            t_chk, (q_chk, _, info) = timed(lambda: eng.ik_solve_chunked(one_p, one_q, sc, one_offs, chunk=8, burn_in=24))
+            result["single_clip"] = {
+                "frames": T, "sequential_frames_per_s": T / t_seq, "verified_chunked_frames_per_s": T / t_chk,
+                "chunk": 8, "burn_in": 24, "passes": info["passes"], "resolved_frames": info["resolved_frames"],
+                "max_abs_diff_vs_sequential": float((q_chk - q_seq).abs().max().item()), "includes": "host scheduling + verification passes",
+            }
         if world == 1 and not args.no_cpu:
             from oracle.oracle import Oracle  # checker / comparator only
             orc = Oracle(cm.blob)

@@ -18,9 +18,10 @@ ABI_VERSION = 1
 GMR_DTYPE_F32, GMR_DTYPE_F64 = 0, 1
 
 WORK_ITEM_DTYPE = np.dtype(
-    [("frame_begin", "<i8"), ("n_burn", "<i4"), ("n_out", "<i4"), ("init_row", "<i4"), ("final_row", "<i4")], align=True
+    [("frame_begin", "<i8"), ("n_burn", "<i4"), ("n_out", "<i4"), ("init_row", "<i4"), ("final_row", "<i4"),
+     ("burn_row", "<i4"), ("reserved", "<i4")], align=True
 )
-assert WORK_ITEM_DTYPE.itemsize == 24
+assert WORK_ITEM_DTYPE.itemsize == 32
 
 EXPORTS = ["gmr_abi_version", "gmr_model_create", "gmr_model_destroy", "gmr_last_error", "gmr_model_info_get",
            "gmr_ik_solve", "gmr_fk", "gmr_fk_min_height"]

@@ -475,7 +475,7 @@ int gmr_ik_solve(gmr_model *m, const void *human_pos, const void *human_quat, in
       return GMR_EINVAL;
     }
     tot += w.n_burn + w.n_out; out += w.n_out;
-    need_init |= w.init_row >= 0; need_final |= w.final_row >= 0;
+    need_init |= w.init_row >= 0; need_final |= w.final_row >= 0 || w.burn_row >= 0;
   }
   if (need_init && !qpos_init) { set_err(m, "items reference qpos_init but it is NULL"); return GMR_EINVAL; }
   if (need_final && !qpos_final) { set_err(m, "items reference qpos_final but it is NULL"); return GMR_EINVAL; }

@@ -618,6 +618,8 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
   const int nfr = w.n_burn + w.n_out;
   for (int kf = 0; kf < nfr; ++kf) {
     const int64_t f = w.frame_begin + kf;
+    if (kf == w.n_burn && w.burn_row >= 0 && L.qfinal)  // state the first output frame starts from
+      for (int i = lane; i < nq; i += 64) L.qfinal[(size_t)w.burn_row * nq + i] = q[i];
     GMR_STAMP(10);
     // ---- target preparation (update_targets: scale_human_data + offset_human_data, table-1 offsets) ----
     {

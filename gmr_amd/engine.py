@@ -65,7 +65,8 @@ class Engine:
     # ------------------------------------------------------------------
     def ik_solve(self, pos: torch.Tensor, quat: torch.Tensor, slot_col: np.ndarray, items: np.ndarray,
                  params: Optional[IKParams] = None, qpos_init: Optional[torch.Tensor] = None, n_final: int = 0,
-                 want_iters: bool = True, out: Optional[torch.Tensor] = None):
+                 want_iters: bool = True, out: Optional[torch.Tensor] = None, qpos_final: Optional[torch.Tensor] = None,
+                 iters: Optional[torch.Tensor] = None):
         """pos [N,B,3], quat [N,B,4] (float32 or float64 CUDA tensors) -> qpos [N,nq] float64.
 
         Frames not covered by any item's output range are left as NaN.  Returns (qpos, iters or None, qpos_final or None).
@@ -87,15 +88,23 @@ class Engine:
             out = torch.full((N, self.nq), float("nan"), dtype=torch.float64, device=self.device)
         elif out.shape != (N, self.nq) or out.dtype != torch.float64 or not out.is_contiguous() or out.device != self.device:
             raise EngineError("out must be a contiguous float64 [N, nq] tensor on the engine's device")
-        iters = torch.zeros(N, dtype=torch.int32, device=self.device) if want_iters else None
-        qfin = torch.zeros((n_final, self.nq), dtype=torch.float64, device=self.device) if n_final > 0 else None
+        if iters is None:
+            iters = torch.zeros(N, dtype=torch.int32, device=self.device) if want_iters else None
+        if qpos_final is not None:
+            if qpos_final.dtype != torch.float64 or qpos_final.dim() != 2 or qpos_final.shape[1] != self.nq or not qpos_final.is_contiguous() \
+                    or qpos_final.device != self.device:
+                raise EngineError("qpos_final must be a contiguous float64 [R, nq] tensor on the engine's device")
+            qfin, n_final = qpos_final, int(qpos_final.shape[0])
+        else:
+            qfin = torch.zeros((n_final, self.nq), dtype=torch.float64, device=self.device) if n_final > 0 else None
         if qpos_init is not None:
             if qpos_init.dtype != torch.float64 or qpos_init.dim() != 2 or qpos_init.shape[1] != self.nq or qpos_init.device != self.device:
                 raise EngineError("qpos_init must be float64 [R, nq] on the engine's device")
-            qpos_init = qpos_init.contiguous()
+            if not qpos_init.is_contiguous():
+                qpos_init = qpos_init.contiguous()
             if len(items) and int(items["init_row"].max()) >= qpos_init.shape[0]:
                 raise EngineError("init_row outside qpos_init")
-        if len(items) and int(items["final_row"].max()) >= n_final:
+        if len(items) and int(max(items["final_row"].max(), items["burn_row"].max())) >= n_final:
             raise EngineError("final_row outside qpos_final")
         stats = IKStats()
         rc = self._lib.gmr_ik_solve(
@@ -105,6 +114,68 @@ class Engine:
         self._check(rc, "gmr_ik_solve")
         self.last_stats = stats
         return out, iters, qfin
+
+    def ik_solve_chunked(self, pos: torch.Tensor, quat: torch.Tensor, slot_col: np.ndarray, seq_offsets, chunk: int, burn_in: int,
+                         params: Optional[IKParams] = None, eps: float = 1e-7, max_passes: int = 64):
+        """Parallel-in-time solve of long clips with *verified* chunk boundaries.
+
+        Pass 0 solves every chunk of ``chunk`` frames concurrently, each (but a clip's first) warmed up over
+        ``burn_in`` earlier frames from ``qpos0``.  A chunk is accepted only if the state its first output frame
+        started from equals its predecessor's final state to ``eps`` and the predecessor is accepted; runs of
+        rejected chunks are re-solved sequentially from the accepted predecessor's final state (exact continuation),
+        and the check repeats.  The result therefore follows the reference's sequential warm-start semantics to
+        ``eps`` regardless of how well the burn-in worked; burn-in quality only decides how much is re-solved.
+        Returns (qpos [N,nq], iters [N], info dict).
+        """
+        from .schedule import make_items
+        offs = np.asarray(seq_offsets, dtype=np.int64)
+        items = make_items(offs, chunk=chunk, burn_in=burn_in, track=True)
+        n = len(items)
+        out, iters, qf = self.ik_solve(pos, quat, slot_col, items, params=params, n_final=2 * n)
+        info = {"chunks": n, "passes": 0, "resolved_frames": 0, "first_pass_rejected": 0}
+        if n == 0:
+            return out, iters, info
+        out_begin = items["frame_begin"] + items["n_burn"]
+        is_first = np.isin(out_begin, offs[:-1])
+        pred = np.arange(n) - 1
+        cons_idx = torch.from_numpy(np.nonzero(~is_first)[0]).to(self.device)
+        pred_idx = torch.from_numpy(pred[~is_first]).to(self.device)
+        accepted = is_first.copy()  # exact by construction: a clip's first chunk, and every chunk of a re-solved run
+        for p in range(max_passes + 1):
+            cons = np.ones(n, dtype=bool)
+            if len(cons_idx):
+                d = (qf[n + cons_idx] - qf[pred_idx]).abs().amax(dim=1)
+                cons[~is_first] = (d < eps).cpu().numpy()
+            runs = []  # maximal runs [i, j) of rejected chunks directly behind an accepted one
+            i = 0
+            while i < n:
+                if accepted[i]:
+                    i += 1
+                elif accepted[i - 1] and cons[i]:
+                    accepted[i] = True
+                    i += 1
+                elif accepted[i - 1]:
+                    j = i + 1
+                    while j < n and not accepted[j] and not cons[j]:
+                        j += 1
+                    runs.append((i, j))
+                    i = j
+                else:  # predecessor not accepted yet: decided in a later pass
+                    i += 1
+            if p == 0:
+                info["first_pass_rejected"] = int(sum(j - i for i, j in runs))
+            if accepted.all():
+                break
+            if not runs or p == max_passes:
+                raise EngineError("chunk verification did not converge")
+            redo = np.zeros(len(runs), dtype=_native.WORK_ITEM_DTYPE)
+            for k, (i, j) in enumerate(runs):
+                redo[k] = (out_begin[i], 0, int(items["n_out"][i:j].sum()), i - 1, j - 1, n + i, 0)
+                info["resolved_frames"] += int(redo[k]["n_out"])
+                accepted[i:j] = True
+            self.ik_solve(pos, quat, slot_col, redo, params=params, qpos_init=qf, qpos_final=qf, out=out, iters=iters)
+            info["passes"] += 1
+        return out, iters, info
 
     def fk(self, root_pos: torch.Tensor, root_rot_xyzw: torch.Tensor, dof: torch.Tensor, want_rot: bool = True):
         for t in (root_pos, root_rot_xyzw, dof):

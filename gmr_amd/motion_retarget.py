@@ -114,6 +114,7 @@ class GeneralMotionRetargeting:
         self._item1["n_out"] = 1
         self._item1["init_row"] = 0
         self._item1["final_row"] = 0
+        self._item1["burn_row"] = -1
 
     def _params(self, offset_to_ground: bool) -> IKParams:
         return IKParams(damping=self.damping, max_iter=self.max_iter, offset_to_ground=int(bool(offset_to_ground)))
@@ -157,12 +158,14 @@ class GeneralMotionRetargeting:
 
     # ------------------------------------------------------------------ batched API
     def retarget_batch(self, pos, quat, body_names: Sequence[str], seq_offsets=None, chunk: int = 0, burn_in: int = 0,
-                       offset_to_ground: bool = False, return_iters: bool = False):
+                       offset_to_ground: bool = False, return_iters: bool = False, verify: bool = True):
         """Retarget whole clips in one launch.
 
         pos ``[N, B, 3]`` (m), quat ``[N, B, 4]`` (wxyz), float32/float64, numpy or CUDA torch; ``body_names`` names the
         B columns; ``seq_offsets [S+1]`` delimits independent clips (default: one clip).  Every clip starts from
-        ``qpos0`` like a fresh reference object.  ``chunk``/``burn_in`` enable time-chunking (see schedule.py).
+        ``qpos0`` like a fresh reference object.  ``chunk > 0`` solves each clip in parallel-in-time chunks; with ``verify``
+        (default) chunk boundaries are checked and repaired so the result equals the sequential run to 1e-7
+        (``Engine.ik_solve_chunked``); ``verify=False`` is the raw burn-in approximation (schedule.py).
         Returns qpos ``[N, nq]`` float64 (same container kind as the input) and, optionally, solves per frame.
         """
         is_np = isinstance(pos, np.ndarray)
@@ -175,8 +178,12 @@ class GeneralMotionRetargeting:
         offs = np.asarray(seq_offsets, dtype=np.int64)
         if offs[0] != 0 or offs[-1] != N:
             raise ValueError("seq_offsets must span [0, N]")
-        items = make_items(offs, chunk=chunk, burn_in=burn_in)
-        out, iters, _ = self._engine.ik_solve(tpos, tquat, self._columns(list(body_names)), items, params=self._params(offset_to_ground))
+        if chunk > 0 and verify:
+            out, iters, self.last_chunk_info = self._engine.ik_solve_chunked(
+                tpos, tquat, self._columns(list(body_names)), offs, chunk, burn_in, params=self._params(offset_to_ground))
+        else:
+            items = make_items(offs, chunk=chunk, burn_in=burn_in)
+            out, iters, _ = self._engine.ik_solve(tpos, tquat, self._columns(list(body_names)), items, params=self._params(offset_to_ground))
         if is_np:
             out = out.cpu().numpy()
             iters = iters.cpu().numpy() if iters is not None else None

@@ -23,7 +23,7 @@ import numpy as np
 from ._native import WORK_ITEM_DTYPE
 
 
-def make_items(seq_offsets: Sequence[int], chunk: int = 0, burn_in: int = 0) -> np.ndarray:
+def make_items(seq_offsets: Sequence[int], chunk: int = 0, burn_in: int = 0, track: bool = False) -> np.ndarray:
     offs = np.asarray(seq_offsets, dtype=np.int64)
     if offs.ndim != 1 or offs.size < 1 or np.any(np.diff(offs) < 0):
         raise ValueError("seq_offsets must be a non-decreasing 1-D array")
@@ -33,13 +33,18 @@ def make_items(seq_offsets: Sequence[int], chunk: int = 0, burn_in: int = 0) -> 
         if b == a:
             continue
         if chunk <= 0:
-            rows.append((a, 0, b - a, -1, -1))
+            rows.append((a, 0, b - a, -1, -1, -1, 0))
             continue
         for start in range(a, b, chunk):
             n_out = min(chunk, b - start)
             burn = min(burn_in, start - a)
-            rows.append((start - burn, burn, n_out, -1, -1))
-    return np.array(rows, dtype=WORK_ITEM_DTYPE) if rows else np.zeros(0, dtype=WORK_ITEM_DTYPE)
+            rows.append((start - burn, burn, n_out, -1, -1, -1, 0))
+    items = np.array(rows, dtype=WORK_ITEM_DTYPE) if rows else np.zeros(0, dtype=WORK_ITEM_DTYPE)
+    if track:  # final state of item i -> row i, state after burn-in -> row n + i (see verified_chunked_solve)
+        n = len(items)
+        items["final_row"] = np.arange(n)
+        items["burn_row"] = n + np.arange(n)
+    return items
 
 
 def partition_clips(lengths: Sequence[int], world_size: int) -> List[List[int]]:

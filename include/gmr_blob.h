@@ -70,7 +70,8 @@ typedef struct gmr_blob_header {
 
 /* One unit of IK work: a run of consecutive frames of one clip, processed in
  * time order with warm start.  The first n_burn frames only warm the state up
- * (no output); the following n_out frames write qpos_out[frame].
+ * (no output); the following n_out frames write qpos_out[frame].  burn_row lets a
+ * caller check a chunk's warm-up against its predecessor's final state.
  * init_row >= 0 starts from qpos_init[init_row], otherwise from qpos0
  * (reference: a fresh GeneralMotionRetargeting per clip, motion_retarget.py:75). */
 typedef struct gmr_work_item {
@@ -79,6 +80,9 @@ typedef struct gmr_work_item {
   int32_t n_out;
   int32_t init_row;    /* row of qpos_init, or -1                              */
   int32_t final_row;   /* row of qpos_final to receive the last state, or -1   */
+  int32_t burn_row;    /* row of qpos_final to receive the state right before  */
+                       /* the first output frame (after burn-in), or -1        */
+  int32_t reserved;
 } gmr_work_item;
 
 /* Solver constants; defaults are the reference's hard-coded values. */

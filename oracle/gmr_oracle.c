@@ -614,6 +614,7 @@ int oracle_ik_solve(const oracle_model *m, const gmr_ik_params *prm, const void 
     memcpy(q, w->init_row >= 0 ? qpos_init + (size_t)w->init_row * nq : m->qpos0, nq * sizeof(double));
     for (int k = 0; k < w->n_burn + w->n_out; k++) {
       int64_t f = w->frame_begin + k;
+      if (k == w->n_burn && w->burn_row >= 0 && qpos_final) memcpy(qpos_final + (size_t)w->burn_row * nq, q, nq * sizeof(double));
       gather_frame(pos, quat, in_f64, n_cols, slot_col, ns, f, hp, hq);
       int s = oracle_retarget_frame(m, prm, q, hp, hq, NULL);
       if (s < 0) fail |= 1;

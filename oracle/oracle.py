@@ -30,13 +30,15 @@ class IKParams(C.Structure):
 
 
 WORK_ITEM_DTYPE = np.dtype(
-    [("frame_begin", "<i8"), ("n_burn", "<i4"), ("n_out", "<i4"), ("init_row", "<i4"), ("final_row", "<i4")], align=True
+    [("frame_begin", "<i8"), ("n_burn", "<i4"), ("n_out", "<i4"), ("init_row", "<i4"), ("final_row", "<i4"),
+     ("burn_row", "<i4"), ("reserved", "<i4")], align=True
 )
 
 
 def build(force: bool = False) -> str:
     src = os.path.join(HERE, "gmr_oracle.c")
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+    hdr = os.path.join(os.path.dirname(HERE), "include", "gmr_blob.h")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         subprocess.check_call(["make", "-C", HERE, "-s"])
     return LIB_PATH
 
@@ -187,7 +189,7 @@ class Oracle:
         qout = np.full((N, self.nq), np.nan)
         iters = np.zeros(N, dtype=np.int32)
         qi = _c64(qpos_init) if qpos_init is not None else None
-        nfin = int(items["final_row"].max()) + 1 if len(items) else 0
+        nfin = int(max(items["final_row"].max(), items["burn_row"].max())) + 1 if len(items) else 0
         qf = np.zeros((max(nfin, 1), self.nq)) if want_final else None
         rc = lib().oracle_ik_solve(
             self._h, C.byref(prm), pos.ctypes.data, quat.ctypes.data, int(pos.dtype == np.float64), n_cols, _i(slot_col),

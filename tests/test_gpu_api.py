@@ -96,6 +96,23 @@ def test_full_length_clip_matches_oracle_and_chunking_residual():
             d = np.abs(q_c - q_seq)
             rec[f"{'hard' if hard else 'easy'}_chunk{chunk}_burn{burn}"] = {
                 "max_abs": float(d.max()), "p999": float(np.quantile(d.max(axis=1), 0.999)), "frames_over_1e-3": int((d.max(axis=1) > 1e-3).sum())}
+        # verified parallel-in-time: same chunks, boundaries checked against the predecessor and repaired
+        import time
+        for chunk, burn in ((16, 32), (8, 24), (32, 32)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            q_v, it_v, info = eng.ik_solve_chunked(tp, tq, sc, offs, chunk=chunk, burn_in=burn)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            dv = np.abs(q_v.cpu().numpy() - q_seq)
+            assert dv.max() < 1e-6, (chunk, burn, dv.max(), info)
+            rec[f"{'hard' if hard else 'easy'}_verified_chunk{chunk}_burn{burn}"] = dict(info, max_abs=float(dv.max()), seconds=dt,
+                                                                                     frames_per_s=3000 / dt)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.ik_solve(tp, tq, sc, make_items(offs))
+        torch.cuda.synchronize()
+        rec[f"{'hard' if hard else 'easy'}_sequential_seconds"] = time.perf_counter() - t0
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "chunk_residual.json"), "w") as f:
         json.dump(rec, f, indent=1)

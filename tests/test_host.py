@@ -126,6 +126,8 @@ def test_make_items_and_partition():
     assert it["frame_begin"].tolist() == [0, 5] and it["n_out"].tolist() == [5, 7] and it["n_burn"].tolist() == [0, 0]
     it = make_items([0, 10], chunk=4, burn_in=3)
     assert it["frame_begin"].tolist() == [0, 1, 5] and it["n_burn"].tolist() == [0, 3, 3] and it["n_out"].tolist() == [4, 4, 2]
+    tr = make_items([0, 10], chunk=4, burn_in=3, track=True)
+    assert tr["final_row"].tolist() == [0, 1, 2] and tr["burn_row"].tolist() == [3, 4, 5] and it["burn_row"].tolist() == [-1, -1, -1]
     covered = np.concatenate([np.arange(r["frame_begin"] + r["n_burn"], r["frame_begin"] + r["n_burn"] + r["n_out"]) for r in it])
     assert covered.tolist() == list(range(10))
     with pytest.raises(ValueError):
@@ -149,7 +151,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.gmr_abi_version() == 1
-    assert ctypes.sizeof(_native.IKParams) == 48 and _native.WORK_ITEM_DTYPE.itemsize == 24
+    assert ctypes.sizeof(_native.IKParams) == 48 and _native.WORK_ITEM_DTYPE.itemsize == 32
 
 
 def test_model_create_fails_loudly_without_a_device():

@@ -202,12 +202,13 @@ def test_work_item_semantics_chunk_equals_sequential_prefix():
     sc = cm.slot_columns(names)
     q_seq, _, _ = orc.ik_solve(pos, quat, sc, make_items(offs, WORK_ITEM_DTYPE))
     it = np.zeros(1, WORK_ITEM_DTYPE)
-    it["frame_begin"], it["n_burn"], it["n_out"], it["init_row"], it["final_row"] = 0, 10, 20, -1, 0
+    it["frame_begin"], it["n_burn"], it["n_out"], it["init_row"], it["final_row"], it["burn_row"] = 0, 10, 20, -1, 0, 1
     q_b, _, qf = orc.ik_solve(pos, quat, sc, it, want_final=True)
     assert np.all(np.isnan(q_b[:10])) and np.array_equal(q_b[10:], q_seq[10:])
     np.testing.assert_array_equal(qf[0], q_seq[-1])
+    np.testing.assert_array_equal(qf[1], q_seq[9])  # burn_row: the state the first output frame starts from
     it2 = np.zeros(1, WORK_ITEM_DTYPE)
-    it2["frame_begin"], it2["n_burn"], it2["n_out"], it2["init_row"], it2["final_row"] = 15, 0, 15, 0, -1
+    it2["frame_begin"], it2["n_burn"], it2["n_out"], it2["init_row"], it2["final_row"], it2["burn_row"] = 15, 0, 15, 0, -1, -1
     q_c, _, _ = orc.ik_solve(pos, quat, sc, it2, qpos_init=q_seq[14:15])
     np.testing.assert_array_equal(q_c[15:], q_seq[15:])
 

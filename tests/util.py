@@ -27,6 +27,7 @@ def make_items(seq_offsets, dtype):
     items["n_out"] = np.diff(seq_offsets)
     items["init_row"] = -1
     items["final_row"] = -1
+    items["burn_row"] = -1
     return items
 
 
