@@ -186,3 +186,42 @@ def test_bad_arguments_are_rejected():
         fk_only.ik_solve(pos, quat, np.zeros(0, np.int32), make_items([0, 4]))
     out, it, _ = eng.ik_solve(pos, quat, sc, make_items([0, 0]))  # empty work: nothing written
     assert torch.isnan(out).all()
+
+
+def test_dataset_path_matches_reference_postprocessing(tmp_path):
+    """retarget_clips == (oracle IK -> reference-convention FK -> the arithmetic of smplx_to_robot_dataset.py:97-141)."""
+    from gmr_amd import GeneralMotionRetargeting as GMR
+    from gmr_amd import dataset
+    g = GMR("smplx", "unitree_g1")
+    cm = g._cm
+    pos, quat, names, offs, _ = synth.synth_clips(cm, 3, 50, seed=3, hard=True, dtype=np.float32)
+    offs = np.array([0, 50, 50, 110, 150])  # ragged, with one empty clip
+    motions = dataset.retarget_clips(g, pos, quat, names, offs, fps=[30, 30, 60, 30])
+    orc = Oracle(cm.blob)
+    q_ref, _, _ = orc.ik_solve(pos, quat, cm.slot_columns(names), make_items(offs))
+    assert len(motions) == 4 and motions[1]["root_pos"].shape == (0, 3)
+    for s, mo in enumerate(motions):
+        a, b = offs[s], offs[s + 1]
+        q = q_ref[a:b]
+        dataset.validate_motion(mo, nq=36)
+        assert mo["fps"] == [30, 30, 60, 30][s] and mo["link_body_list"] == cm.robot.body_names
+        if b == a:
+            continue
+        root_rot = q[:, [4, 5, 6, 3]]
+        ident = np.tile(np.array([[0, 0, 0, 1]], np.float32), (b - a, 1))
+        local, _ = orc.fk_kin(np.zeros((b - a, 3), np.float32), ident, q[:, 7:].astype(np.float32), want_rot=False)
+        body, _ = orc.fk_kin(q[:, :3].astype(np.float32), root_rot.astype(np.float32), q[:, 7:].astype(np.float32), want_rot=False)
+        root_pos = q[:, :3].copy()
+        root_pos[:, 2] -= float(body[..., 2].min())
+        root_pos[:, :2] -= root_pos[0, :2]
+        assert mo["root_pos"].dtype == np.float64 and mo["local_body_pos"].dtype == np.float32
+        assert np.abs(mo["root_pos"] - root_pos).max() < 5e-6   # float32 FK feeds the height
+        assert np.abs(mo["root_rot"] - root_rot).max() < 1e-6 and np.abs(mo["dof_pos"] - q[:, 7:]).max() < 1e-6
+        assert np.abs(mo["local_body_pos"] - local).max() < 5e-6
+        assert abs(mo["root_pos"][0, 0]) < 1e-12 and abs(mo["root_pos"][0, 1]) < 1e-12
+    p = tmp_path / "clip.pkl"
+    assert dataset.save_motion(str(p), motions[0]) and not dataset.save_motion(str(p), motions[0])
+    d, fps, rp, rr_wxyz, dp, lb, names_out = dataset.load_robot_motion(str(p))
+    assert fps == 30 and np.array_equal(rr_wxyz[:, [1, 2, 3, 0]], motions[0]["root_rot"]) and names_out == cm.robot.body_names
+    bvh = dataset.retarget_clips(g, pos[:50], quat[:50], names, [0, 50], height_adjust=False, root_origin_offset=False)
+    assert np.abs(bvh[0]["root_pos"] - q_ref[:50, :3]).max() < 1e-6
