@@ -1,0 +1,178 @@
+"""BVH input adapter on the fast path.
+
+Mirror of ``load_lafan1_file`` (reference general_motion_retargeting/utils/lafan1.py:8-71) with the reference's
+own file semantics (``read_bvh``, utils/lafan_vendor/extract.py:43-166): hierarchy parsed line by line, the Euler
+order taken from the first CHANNELS line, the channel count from the last one, root translation from the first three
+motion columns, non-root local positions = joint offsets.  The text is parsed on the host (numpy's C tokenizer for the
+motion block); Euler -> quaternion, the quaternion FK, the Y-up -> Z-up turn, cm -> m and the ``LeftFootMod`` /
+``RightFootMod`` synthesis run in one HIP kernel (``gmr_bvh_fk``) and the result stays on the GPU as the
+``[T, B, 3]`` / ``[T, B, 4]`` tensors ``retarget_batch`` consumes -- no per-frame dicts unless asked for.
+
+Differences from the reference: quaternion signs are not made continuous in time (``remove_quat_discontinuities``
+only flips signs; every consumer is sign-insensitive); 9-channel files are rejected.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import re
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+
+from . import _native
+
+_CHANNEL = {"Xrotation": 0, "Yrotation": 1, "Zrotation": 2}
+
+
+class BvhAnim:
+    def __init__(self, names, parents, offsets, order, positions, eulers_deg, frametime):
+        self.bones: List[str] = names
+        self.parents: np.ndarray = parents          # int32 [J]
+        self.offsets: np.ndarray = offsets          # [J,3]
+        self.order: Tuple[int, int, int] = order    # axis index of the three listed rotation channels
+        self.pos: np.ndarray = positions            # local positions [T,J,3]
+        self.eulers_deg: np.ndarray = eulers_deg    # [T,J,3]
+        self.frametime = frametime
+
+
+def read_bvh(filename: str) -> BvhAnim:
+    with open(filename, "r") as f:
+        lines = f.read().split("\n")
+    names: List[str] = []
+    offsets: List[List[float]] = []
+    parents: List[int] = []
+    active, end_site, order, channels, fnum, frametime = -1, False, None, None, None, None
+    i = 0
+    while i < len(lines):
+        line = lines[i]
+        i += 1
+        if "HIERARCHY" in line or "MOTION" in line:
+            continue
+        m = re.match(r"ROOT (\w+)", line) or re.match(r"\s*JOINT\s+(\w+)", line)
+        if m:
+            names.append(m.group(1))
+            offsets.append([0.0, 0.0, 0.0])
+            parents.append(active)
+            active = len(parents) - 1
+            continue
+        if "{" in line:
+            continue
+        if "}" in line:
+            if end_site:
+                end_site = False
+            else:
+                active = parents[active]
+            continue
+        m = re.match(r"\s*OFFSET\s+([\-\d\.e]+)\s+([\-\d\.e]+)\s+([\-\d\.e]+)", line)
+        if m:
+            if not end_site:
+                offsets[active] = [float(x) for x in m.groups()]
+            continue
+        m = re.match(r"\s*CHANNELS\s+(\d+)", line)
+        if m:
+            channels = int(m.group(1))
+            if order is None:
+                lo, hi = (0, 3) if channels == 3 else (3, 6)
+                parts = line.split()[2 + lo:2 + hi]
+                if all(p in _CHANNEL for p in parts):
+                    order = tuple(_CHANNEL[p] for p in parts)
+            continue
+        if "End Site" in line:
+            end_site = True
+            continue
+        m = re.match(r"\s*Frames:\s+(\d+)", line)
+        if m:
+            fnum = int(m.group(1))
+            continue
+        m = re.match(r"\s*Frame Time:\s+([\d\.]+)", line)
+        if m:
+            frametime = float(m.group(1))
+            break
+    if fnum is None or order is None or channels is None or not names:
+        raise ValueError(f"{filename}: not a BVH file this loader understands")
+    J = len(names)
+    body = [ln for ln in lines[i:] if ln.strip()]
+    if len(body) < fnum:
+        raise ValueError(f"{filename}: {len(body)} motion rows, header says {fnum}")
+    data = np.array(" ".join(body[:fnum]).split(), dtype=np.float64).reshape(fnum, -1)
+    offs = np.asarray(offsets, dtype=np.float64)
+    positions = np.repeat(offs[None], fnum, axis=0)
+    if channels == 3:
+        if data.shape[1] != 3 + 3 * J:
+            raise ValueError(f"{filename}: expected {3 + 3 * J} columns, found {data.shape[1]}")
+        positions[:, 0] = data[:, 0:3]
+        rotations = data[:, 3:].reshape(fnum, J, 3)
+    elif channels == 6:
+        if data.shape[1] != 6 * J:
+            raise ValueError(f"{filename}: expected {6 * J} columns, found {data.shape[1]}")
+        blk = data.reshape(fnum, J, 6)
+        positions = blk[:, :, 0:3].copy()
+        rotations = blk[:, :, 3:6].copy()
+    else:
+        raise NotImplementedError(f"{filename}: {channels}-channel joints are not supported")
+    return BvhAnim(names, np.asarray(parents, dtype=np.int32), offs, order, positions, rotations, frametime)
+
+
+class BvhClip:
+    """Global joint poses of one BVH clip on the GPU, in the layout ``retarget_batch`` takes."""
+
+    def __init__(self, pos: torch.Tensor, quat: torch.Tensor, names: List[str], human_height: float, frametime):
+        self.pos, self.quat, self.body_names, self.human_height, self.frametime = pos, quat, names, human_height, frametime
+
+    def __len__(self):
+        return int(self.pos.shape[0])
+
+    def frames(self) -> List[Dict[str, Tuple[np.ndarray, np.ndarray]]]:
+        """The reference's return shape: one dict ``{bone: (position[3], quat_wxyz[4])}`` per frame."""
+        p, q = self.pos.cpu().numpy(), self.quat.cpu().numpy()
+        return [{n: (p[t, i], q[t, i]) for i, n in enumerate(self.body_names)} for t in range(p.shape[0])]
+
+
+def _estimate_height(last: Dict[str, np.ndarray]) -> float:
+    """lafan1.py:45-69 on the last frame's positions."""
+    if not last:
+        return 1.75
+    if "Head" in last:
+        feet = [last[k][2] for k in ("LeftFootMod", "RightFootMod", "LeftFoot", "RightFoot") if k in last]
+        h = last["Head"][2] - (min(feet) if feet else min(v[2] for v in last.values()))
+    else:
+        z = [v[2] for v in last.values()]
+        h = max(z) - min(z)
+    if not np.isfinite(h) or h < 0.9 or h > 2.3:
+        h = 1.75
+    return float(h)
+
+
+def load_lafan1_file(bvh_file: str, device: int = 0) -> BvhClip:
+    """BVH file -> global poses (metres, Z-up, wxyz) on ``cuda:device`` + the reference's height estimate."""
+    anim = read_bvh(bvh_file)
+    lib = _native.load()
+    dev = torch.device("cuda", device)
+    T, J = anim.pos.shape[0], len(anim.bones)
+    extra_names, extra_pos, extra_rot = [], [], []
+    for side in ("Left", "Right"):
+        if f"{side}Foot" in anim.bones and f"{side}Toe" in anim.bones:  # lafan1.py:36-39
+            extra_names.append(f"{side}FootMod")
+            extra_pos.append(anim.bones.index(f"{side}Foot"))
+            extra_rot.append(anim.bones.index(f"{side}Toe"))
+    E = len(extra_names)
+    lp = torch.from_numpy(np.ascontiguousarray(anim.pos)).to(dev)
+    er = torch.from_numpy(np.ascontiguousarray(np.radians(anim.eulers_deg))).to(dev)
+    pos = torch.empty((T, J + E, 3), dtype=torch.float64, device=dev)
+    quat = torch.empty((T, J + E, 4), dtype=torch.float64, device=dev)
+    parents = np.ascontiguousarray(anim.parents, dtype=np.int32)
+    order = np.asarray(anim.order, dtype=np.int32)
+    ep, erot = np.asarray(extra_pos, dtype=np.int32), np.asarray(extra_rot, dtype=np.int32)
+    vp = C.c_void_p
+    rc = lib.gmr_bvh_fk(parents.ctypes.data_as(vp), J, order.ctypes.data_as(vp), ep.ctypes.data_as(vp) if E else None,
+                        erot.ctypes.data_as(vp) if E else None, E, vp(lp.data_ptr()), vp(er.data_ptr()), T, 0.01,
+                        vp(pos.data_ptr()), vp(quat.data_ptr()), vp(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"gmr_bvh_fk failed with status {rc} ({J} joints, {E} extra)")
+    names = list(anim.bones) + extra_names
+    height = 1.75
+    if T > 0:
+        last = pos[-1].cpu().numpy()
+        height = _estimate_height({n: last[i] for i, n in enumerate(names)})
+    return BvhClip(pos, quat, names, height, anim.frametime)

@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#include "bvh_kernel.hip.h"
 #include "fk_kernel.hip.h"
 #include "ik_kernel.hip.h"
 
@@ -557,6 +558,35 @@ int gmr_fk_min_height(gmr_model *m, const float *root_pos, const float *root_rot
   hipLaunchKernelGGL(gmr::fk_minkey_decode, dim3((n_seq + 255) / 256), dim3(256), 0, st, keys, min_z_out, n_seq);
   HIP_TRY(m, hipGetLastError());
   return GMR_OK;
+}
+
+int gmr_bvh_fk(const int32_t *parents, int n_joints, const int32_t *euler_order, const int32_t *extra_pos_src,
+               const int32_t *extra_rot_src, int n_extra, const double *local_pos, const double *euler_rad, int64_t n_frames,
+               double scale, double *pos_out, double *quat_out, void *stream) {
+  if (!parents || !euler_order || !local_pos || !euler_rad || !pos_out || !quat_out || n_frames < 0) return GMR_EINVAL;
+  if (n_joints < 1 || n_joints > gmr::kBvhMaxJoints || n_extra < 0 || n_extra > gmr::kBvhMaxExtra) return GMR_EUNSUPPORTED;
+  if (n_extra > 0 && (!extra_pos_src || !extra_rot_src)) return GMR_EINVAL;
+  gmr::BvhSkeleton sk{};
+  sk.n_joints = n_joints; sk.n_extra = n_extra;
+  for (int i = 0; i < 3; ++i) {
+    if (euler_order[i] < 0 || euler_order[i] > 2) return GMR_EINVAL;
+    sk.order[i] = euler_order[i];
+  }
+  if (parents[0] != -1) return GMR_EINVAL;
+  for (int j = 0; j < n_joints; ++j) {
+    if (j > 0 && (parents[j] < 0 || parents[j] >= j)) return GMR_EINVAL;  // hierarchy order
+    sk.parent[j] = (short)parents[j];
+  }
+  for (int k = 0; k < n_extra; ++k) {
+    if (extra_pos_src[k] < 0 || extra_pos_src[k] >= n_joints || extra_rot_src[k] < 0 || extra_rot_src[k] >= n_joints) return GMR_EINVAL;
+    sk.extra_pos_src[k] = (short)extra_pos_src[k]; sk.extra_rot_src[k] = (short)extra_rot_src[k];
+  }
+  if (n_frames == 0) return GMR_OK;
+  const int64_t nblk = (n_frames + 127) / 128;
+  if (nblk > 0x7fffffff) return GMR_EINVAL;
+  hipLaunchKernelGGL(gmr::bvh_fk_kernel, dim3((unsigned)nblk), dim3(128), 0, static_cast<hipStream_t>(stream), sk, local_pos, euler_rad,
+                     n_frames, scale, pos_out, quat_out);
+  return hipGetLastError() == hipSuccess ? GMR_OK : GMR_EDEVICE;
 }
 
 #ifdef GMR_IK_STAMPS

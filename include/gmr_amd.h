@@ -24,6 +24,9 @@
  *   gmr_fk             KinematicsModel.forward_kinematics (kinematics_model.py:213-246)
  *   gmr_fk_min_height  the clip-global `torch.min(body_pos[..., 2])` of the height adjust
  *                      (scripts/smplx_to_robot_dataset.py:118-126)
+ *   gmr_bvh_fk         the numeric part of load_lafan1_file (general_motion_retargeting/utils/lafan1.py:8-40):
+ *                      euler_to_quat + quat_fk (utils/lafan_vendor/utils.py:56-103), Y-up -> Z-up, cm -> m,
+ *                      LeftFootMod / RightFootMod synthesis
  */
 #ifndef GMR_AMD_H
 #define GMR_AMD_H
@@ -104,6 +107,17 @@ int gmr_fk(gmr_model *m, const float *root_pos, const float *root_rot_xyzw, cons
  *   seq_offsets host [n_seq+1]; min_z_out device [n_seq] float32                    */
 int gmr_fk_min_height(gmr_model *m, const float *root_pos, const float *root_rot_xyzw, const float *dof,
                       const int64_t *seq_offsets, int n_seq, float *min_z_out, void *stream);
+
+/* BVH skeleton FK (stateless).  Joints in hierarchy order (parents[0] = -1, parents[j] < j), one Euler triple per joint.
+ *   parents, euler_order[3] (0=x,1=y,2=z, the order the channels are listed), extra_*_src[n_extra]: host
+ *   local_pos  device [n_frames][n_joints][3]  local translations (file units)
+ *   euler_rad  device [n_frames][n_joints][3]  channel angles in radians
+ *   pos_out    device [n_frames][n_joints+n_extra][3]  = scale * (global position rotated to Z-up)
+ *   quat_out   device [n_frames][n_joints+n_extra][4]  wxyz, rotated to Z-up
+ * Extra entry k takes the position of joint extra_pos_src[k] and the orientation of joint extra_rot_src[k].        */
+int gmr_bvh_fk(const int32_t *parents, int n_joints, const int32_t *euler_order, const int32_t *extra_pos_src,
+               const int32_t *extra_rot_src, int n_extra, const double *local_pos, const double *euler_rad, int64_t n_frames,
+               double scale, double *pos_out, double *quat_out, void *stream);
 
 #ifdef __cplusplus
 }

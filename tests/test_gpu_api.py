@@ -225,3 +225,33 @@ def test_dataset_path_matches_reference_postprocessing(tmp_path):
     assert fps == 30 and np.array_equal(rr_wxyz[:, [1, 2, 3, 0]], motions[0]["root_rot"]) and names_out == cm.robot.body_names
     bvh = dataset.retarget_clips(g, pos[:50], quat[:50], names, [0, 50], height_adjust=False, root_origin_offset=False)
     assert np.abs(bvh[0]["root_pos"] - q_ref[:50, :3]).max() < 1e-6
+
+
+@pytest.mark.parametrize("name", ["bvh_canonical_40f", "bvh_lafan_like"])
+def test_bvh_adapter_matches_reference_loader(name, golden_dir):
+    """gmr_amd.bvh.load_lafan1_file (host parse + gmr_bvh_fk) vs the reference's load_lafan1_file output (golden)."""
+    from gmr_amd.bvh import load_lafan1_file
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    clip = load_lafan1_file(os.path.join(golden_dir, name + ".bvh"))
+    assert clip.body_names == [str(n) for n in g["names"]]
+    assert abs(clip.human_height - float(g["human_height"])) < 1e-9
+    pos, quat = clip.pos.cpu().numpy(), clip.quat.cpu().numpy()
+    assert np.abs(pos - g["pos"]).max() < 1e-9
+    # the reference removes sign flips along time on the local quaternions; rotations are identical up to sign
+    d = np.minimum(np.abs(quat - g["quat"]).max(axis=-1), np.abs(quat + g["quat"]).max(axis=-1))
+    assert d.max() < 1e-9
+    fr = clip.frames()
+    assert len(fr) == len(clip) and set(fr[0].keys()) == set(clip.body_names) and fr[3]["Hips" if "Hips" in fr[0] else clip.body_names[0]][0].shape == (3,)
+
+
+def test_bvh_to_robot_end_to_end(golden_dir):
+    """bvh_to_robot_dataset.py path: BVH file -> GPU adapter -> batched IK (bvh_to_g1 config) == oracle on the golden poses."""
+    from gmr_amd import GeneralMotionRetargeting as GMR
+    from gmr_amd.bvh import load_lafan1_file
+    clip = load_lafan1_file(os.path.join(golden_dir, "bvh_lafan_like.bvh"))
+    g = GMR(src_human="bvh", tgt_robot="unitree_g1", actual_human_height=clip.human_height)
+    q = g.retarget_batch(clip.pos, clip.quat, clip.body_names)
+    gold = np.load(os.path.join(golden_dir, "bvh_lafan_like.npz"))
+    cm = g._cm
+    q_ref, _, _ = Oracle(cm.blob).ik_solve(gold["pos"], gold["quat"], cm.slot_columns([str(n) for n in gold["names"]]), make_items([0, len(clip)]))
+    assert np.abs(q.cpu().numpy() - q_ref).max() < 1e-6

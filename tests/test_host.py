@@ -171,3 +171,19 @@ def test_model_create_fails_loudly_without_a_device():
     from gmr_amd.engine import Engine, EngineError
     with pytest.raises(EngineError):
         Engine(cm, 0)
+
+
+def test_bvh_parser_follows_reference_file_semantics(golden_dir, tmp_path):
+    from gmr_amd.bvh import read_bvh
+    for name, nj in (("bvh_canonical_40f", 101), ("bvh_lafan_like", 22)):
+        a = read_bvh(os.path.join(golden_dir, name + ".bvh"))
+        g = np.load(os.path.join(golden_dir, name + ".npz"))
+        assert a.bones == [str(n) for n in g["names"]][:nj] and a.order == (2, 1, 0)  # "Zrotation Yrotation Xrotation"
+        assert a.parents[0] == -1 and np.all(a.parents[1:] < np.arange(1, nj)) and a.pos.shape == a.eulers_deg.shape == (len(g["pos"]), nj, 3)
+        np.testing.assert_array_equal(a.pos[:, 1:], np.repeat(a.offsets[None, 1:], a.pos.shape[0], axis=0))  # non-root = joint offsets
+        # root translation (cm, Y-up) -> golden root position (m, Z-up): (x, y, z) -> (x, -z, y) / 100
+        np.testing.assert_allclose(np.stack([a.pos[:, 0, 0], -a.pos[:, 0, 2], a.pos[:, 0, 1]], -1) / 100, g["pos"][:, 0], atol=1e-12)
+    bad = tmp_path / "bad.bvh"
+    bad.write_text("HIERARCHY\nROOT a\n{\nOFFSET 0 0 0\nCHANNELS 6 Xposition Yposition Zposition Zrotation Yrotation Xrotation\n}\nMOTION\nFrames: 2\nFrame Time: 0.03\n0 0 0 0 0 0\n")
+    with pytest.raises(ValueError):
+        read_bvh(str(bad))
