@@ -386,6 +386,7 @@ int build_device_model(gmr_model *m) {
   hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<40>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<48>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::eval_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipGetLastError();
   return GMR_OK;
 }
@@ -513,6 +514,41 @@ int gmr_ik_solve(gmr_model *m, const void *human_pos, const void *human_quat, in
     case 64: launch_ik<64>(m, L, st); break;
     default: set_err(m, "internal: no kernel variant for nvp=%d", m->nvp); return GMR_EUNSUPPORTED;
   }
+  HIP_TRY(m, hipGetLastError());
+  return GMR_OK;
+}
+
+int gmr_evaluate(gmr_model *m, const double *qpos, int64_t n_frames, const void *human_pos, const void *human_quat, int in_dtype,
+                 int n_cols, const int32_t *slot_col, int offset_to_ground, double *err_out, double *xpos_out, double *xquat_out,
+                 void *stream) {
+  if (!m) return GMR_EINVAL;
+  m->err.clear();
+  if (!qpos || n_frames < 0) { set_err(m, "null argument / negative size"); return GMR_EINVAL; }
+  if (n_frames > 0x7fffffff) { set_err(m, "too many frames for one launch"); return GMR_EINVAL; }
+  if (err_out) {
+    if (m->h.nslot == 0) { set_err(m, "model has no IK config"); return GMR_ENOCONFIG; }
+    if (!human_pos || !human_quat || !slot_col || n_cols <= 0 || (in_dtype != GMR_DTYPE_F32 && in_dtype != GMR_DTYPE_F64)) {
+      set_err(m, "err_out needs the human key-points, their dtype and slot_col");
+      return GMR_EINVAL;
+    }
+    for (int s = 0; s < m->h.nslot; ++s)
+      if (slot_col[s] < 0 || slot_col[s] >= n_cols) { set_err(m, "slot_col[%d]=%d outside [0,%d)", s, slot_col[s], n_cols); return GMR_EINVAL; }
+  }
+  if (n_frames == 0) return GMR_OK;
+  HIP_TRY(m, hipSetDevice(m->device));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  gmr::EvalLaunch L{};
+  L.qpos = qpos; L.err_out = err_out; L.xpos_out = xpos_out; L.xquat_out = xquat_out; L.n_frames = n_frames;
+  L.offset_to_ground = offset_to_ground;
+  if (err_out) {
+    const size_t col_bytes = sizeof(int32_t) * (size_t)m->h.nslot;
+    int rc = ensure_ws(m, col_bytes);
+    if (rc != GMR_OK) return rc;
+    HIP_TRY(m, hipMemcpyAsync(m->ws, slot_col, col_bytes, hipMemcpyHostToDevice, st));
+    L.hpos = human_pos; L.hquat = human_quat; L.slot_col = static_cast<const int *>(m->ws);
+    L.in_f64 = in_dtype == GMR_DTYPE_F64; L.n_cols = n_cols;
+  }
+  hipLaunchKernelGGL(gmr::eval_kernel, dim3((unsigned)n_frames), dim3(64), m->lds_bytes, st, m->dm, L, m->lay);
   HIP_TRY(m, hipGetLastError());
   return GMR_OK;
 }

@@ -849,4 +849,88 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
 #endif
 }
 
+// ------------------------------------------------------------------ evaluation kernel (no solve)
+// One wavefront per frame: FK in the MuJoCo convention for a given qpos, and the stage errors against the frame's
+// prepared targets -- what `error1()` / `error2()` (motion_retarget.py:188-200) and `configuration.data.xpos` expose
+// in the reference.  err_out [N][2] (0 for a table that is not used), xpos_out [N][nbody][3], xquat_out [N][nbody][4]
+// wxyz; any output may be NULL.
+struct EvalLaunch {
+  const void *hpos, *hquat;  // may be NULL when err_out is NULL
+  const int *slot_col;
+  const double *qpos;        // [N][nq]
+  double *err_out, *xpos_out, *xquat_out;
+  int in_f64, n_cols, offset_to_ground, pad;
+  long long n_frames;
+};
+
+__global__ void __launch_bounds__(64) eval_kernel(const DevModel m, EvalLaunch L, LdsLayout lay) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  const long long f = blockIdx.x;
+  double *q = lds + lay.q, *xpos = lds + lay.xpos, *xquat = lds + lay.xquat, *tp = lds + lay.tp, *tq = lds + lay.tq;
+  double *bodyc = lds + lay.bodyc;
+  const int nq = m.nq, nbody = m.nbody, nslot = m.nslot, root_slot = m.root_slot;
+  if (lane < nbody) {
+    double *bcst = bodyc + kBodyC * lane;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { bcst[i] = m.bpos[3 * lane + i]; bcst[7 + i] = m.axis[3 * lane + i]; }
+#pragma unroll
+    for (int i = 0; i < 4; i++) bcst[3 + i] = m.bquat[4 * lane + i];
+    bcst[10] = __longlong_as_double((long long)((m.fkanc[lane] & 0x0000ffffffffffffull) | ((u64)(m.jtype[lane] & 0xff) << 48) | ((u64)(m.qadr[lane] & 0xff) << 56)));
+  }
+  for (int i = lane; i < nq; i += 64) q[i] = L.qpos[(size_t)f * nq + i];
+  __syncthreads();
+  fk_phase(bodyc, nbody, m.fkrounds, lane, q, xpos, xquat);
+  if (L.xpos_out)
+    for (int i = lane; i < 3 * nbody; i += 64) L.xpos_out[(size_t)f * 3 * nbody + i] = xpos[i];
+  if (L.xquat_out)
+    for (int i = lane; i < 4 * nbody; i += 64) L.xquat_out[(size_t)f * 4 * nbody + i] = xquat[i];
+  if (!L.err_out) return;
+  {  // target preparation, as in ik_kernel
+    const bool is_slot = lane < nslot;
+    const int s_col = L.slot_col[is_slot ? lane : 0], root_col = L.slot_col[root_slot];
+    double hp[3] = {0, 0, 0}, hq[4] = {1, 0, 0, 0}, rp[3];
+    const long long base = f * L.n_cols;
+    if (L.in_f64) {
+      const double *P = (const double *)L.hpos, *Q = (const double *)L.hquat;
+      for (int i = 0; i < 3; i++) { rp[i] = P[(base + root_col) * 3 + i]; hp[i] = P[(base + s_col) * 3 + i]; }
+      for (int i = 0; i < 4; i++) hq[i] = Q[(base + s_col) * 4 + i];
+    } else {
+      const float *P = (const float *)L.hpos, *Q = (const float *)L.hquat;
+      for (int i = 0; i < 3; i++) { rp[i] = (double)P[(base + root_col) * 3 + i]; hp[i] = (double)P[(base + s_col) * 3 + i]; }
+      for (int i = 0; i < 4; i++) hq[i] = (double)Q[(base + s_col) * 4 + i];
+    }
+    double pz = INFINITY, p[3] = {0, 0, 0}, qo[4] = {1, 0, 0, 0}, R[9], g[3];
+    if (is_slot) {
+      const double s_scale = m.sscale[lane], root_scale = m.sscale[root_slot];
+      const double s_poff[3] = {m.spoff[3 * lane], m.spoff[3 * lane + 1], m.spoff[3 * lane + 2]};
+      const double s_roff[4] = {m.sroff[4 * lane], m.sroff[4 * lane + 1], m.sroff[4 * lane + 2], m.sroff[4 * lane + 3]};
+      for (int i = 0; i < 3; i++) p[i] = (lane == root_slot) ? root_scale * rp[i] : (hp[i] - rp[i]) * s_scale + root_scale * rp[i];
+      qnormalize(hq);
+      qmul(hq, s_roff, qo);
+      qrenorm(qo);
+      q2mat(qo, R);
+      mv(R, s_poff, g);
+      for (int i = 0; i < 3; i++) p[i] += g[i];
+      if (m.sfoot[lane]) pz = p[2];
+    }
+    if (L.offset_to_ground) p[2] = p[2] - wave_min(pz) + 0.1;
+    if (is_slot) {
+      for (int i = 0; i < 3; i++) tp[3 * lane + i] = p[i];
+      for (int i = 0; i < 4; i++) tq[4 * lane + i] = qo[i];
+    }
+  }
+  __syncthreads();
+  for (int tab = 0; tab < 2; ++tab) {
+    double err = 0.0;
+    if (m.use_table[tab]) {
+      const bool is_task = lane < m.ntask[tab];
+      const int trow = tab * GMR_MAX_TASKS + (is_task ? lane : 0);
+      double e[6], sh, ch;
+      err = fast_sqrt(wave_sum(is_task ? task_residual(m.tbody[trow], m.tslot[trow], xpos, xquat, tp, tq, e, sh, ch) : 0.0));
+    }
+    if (lane == 0) L.err_out[(size_t)f * 2 + tab] = err;
+  }
+}
+
 }  // namespace gmr

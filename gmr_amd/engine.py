@@ -107,6 +107,9 @@ class Engine:
         if len(items) and int(max(items["final_row"].max(), items["burn_row"].max())) >= n_final:
             raise EngineError("final_row outside qpos_final")
         stats = IKStats()
+        self.last_stats = stats
+        if N == 0 or len(items) == 0:  # nothing to launch (empty tensors have no device pointer)
+            return out, iters, qfin
         rc = self._lib.gmr_ik_solve(
             self._h, _ptr(pos), _ptr(quat), _native.GMR_DTYPE_F64 if pos.dtype == torch.float64 else _native.GMR_DTYPE_F32, B,
             slot_col.ctypes.data_as(C.c_void_p), N, items.ctypes.data_as(C.c_void_p), len(items), C.byref(prm), _ptr(qpos_init),
@@ -176,6 +179,38 @@ class Engine:
             self.ik_solve(pos, quat, slot_col, redo, params=params, qpos_init=qf, qpos_final=qf, out=out, iters=iters)
             info["passes"] += 1
         return out, iters, info
+
+    def evaluate(self, qpos: torch.Tensor, pos: Optional[torch.Tensor] = None, quat: Optional[torch.Tensor] = None,
+                 slot_col: Optional[np.ndarray] = None, offset_to_ground: bool = False, want_errors: bool = True, want_poses: bool = False):
+        """Stage errors [N,2] and/or MuJoCo-convention body poses (xpos [N,nb,3], xquat [N,nb,4] wxyz) at ``qpos`` [N,nq]."""
+        if qpos.device != self.device or qpos.dtype != torch.float64 or qpos.dim() != 2 or qpos.shape[1] != self.nq:
+            raise EngineError("qpos must be float64 [N, nq] on the engine's device")
+        qpos = qpos.contiguous()
+        N = int(qpos.shape[0])
+        err = xp = xq = None
+        B, dt = 0, 0
+        if want_errors:
+            if pos is None or quat is None or slot_col is None:
+                raise EngineError("errors need the human key-points and slot_col")
+            if pos.device != self.device or quat.device != self.device or pos.dtype != quat.dtype or pos.dtype not in (torch.float32, torch.float64) \
+                    or pos.shape[0] != N or pos.shape[:2] != quat.shape[:2] or pos.shape[2] != 3 or quat.shape[2] != 4:
+                raise EngineError("bad key-point tensors")
+            pos, quat = pos.contiguous(), quat.contiguous()
+            slot_col = np.ascontiguousarray(slot_col, dtype=np.int32)
+            if slot_col.shape != (self.info.nslot,):
+                raise EngineError("slot_col has the wrong length")
+            B, dt = int(pos.shape[1]), _native.GMR_DTYPE_F64 if pos.dtype == torch.float64 else _native.GMR_DTYPE_F32
+            err = torch.empty((N, 2), dtype=torch.float64, device=self.device)
+        if want_poses:
+            xp = torch.empty((N, self.nbody, 3), dtype=torch.float64, device=self.device)
+            xq = torch.empty((N, self.nbody, 4), dtype=torch.float64, device=self.device)
+        if N == 0:
+            return err, xp, xq
+        rc = self._lib.gmr_evaluate(self._h, _ptr(qpos), N, _ptr(pos) if want_errors else None, _ptr(quat) if want_errors else None, dt, B,
+                                    slot_col.ctypes.data_as(C.c_void_p) if want_errors else None, int(bool(offset_to_ground)),
+                                    _ptr(err), _ptr(xp), _ptr(xq), self._stream())
+        self._check(rc, "gmr_evaluate")
+        return err, xp, xq
 
     def fk(self, root_pos: torch.Tensor, root_rot_xyzw: torch.Tensor, dof: torch.Tensor, want_rot: bool = True):
         for t in (root_pos, root_rot_xyzw, dof):

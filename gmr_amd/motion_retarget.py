@@ -37,6 +37,15 @@ class _Data:
     def qpos(self) -> np.ndarray:
         return self._o._state.cpu().numpy()[0]
 
+    @property
+    def xpos(self) -> np.ndarray:
+        """World positions of all bodies at the current configuration (MuJoCo ``data.xpos`` without the world body)."""
+        return self._o._engine.evaluate(self._o._state, want_errors=False, want_poses=True)[1].cpu().numpy()[0]
+
+    @property
+    def xquat(self) -> np.ndarray:
+        return self._o._engine.evaluate(self._o._state, want_errors=False, want_poses=True)[2].cpu().numpy()[0]
+
 
 class _Configuration:
     """Stand-in for ``mink.Configuration``: current generalized coordinates only."""
@@ -109,6 +118,7 @@ class GeneralMotionRetargeting:
         self._state = torch.from_numpy(self.model.qpos0.copy()).to(self.device).reshape(1, -1)
         self.configuration = _Configuration(self)
         self.scaled_human_data = None
+        self._last_pos = None
         self._col_cache: Dict[Tuple[str, ...], np.ndarray] = {}
         self._item1 = np.zeros(1, dtype=WORK_ITEM_DTYPE)
         self._item1["n_out"] = 1
@@ -130,6 +140,11 @@ class GeneralMotionRetargeting:
         """Host-side target preparation, kept for callers that read ``scaled_human_data`` (:117-124).
         The solver itself prepares targets on the GPU from the raw key-points."""
         human_data = self.to_numpy(human_data)
+        names = list(human_data.keys())
+        self._last_cols = self._columns(names)
+        self._last_pos = torch.from_numpy(np.stack([np.asarray(human_data[n][0], dtype=np.float64).reshape(3) for n in names])[None]).to(self.device)
+        self._last_quat = torch.from_numpy(np.stack([np.asarray(human_data[n][1], dtype=np.float64).reshape(4) for n in names])[None]).to(self.device)
+        self._last_offset_to_ground = offset_to_ground
         human_data = self.scale_human_data(human_data, self.human_root_name, self.human_scale_table)
         human_data = self.offset_human_data(human_data, self.pos_offsets1, self.rot_offsets1)
         if offset_to_ground:
@@ -146,8 +161,9 @@ class GeneralMotionRetargeting:
         self._last_human_data = human_data
         self._last_offset_to_ground = offset_to_ground
         self.scaled_human_data = _LazyScaled(self)
+        self._last_pos, self._last_quat, self._last_cols = torch.from_numpy(pos).to(self.device), torch.from_numpy(quat).to(self.device), cols
         out, iters, fin = self._engine.ik_solve(
-            torch.from_numpy(pos).to(self.device), torch.from_numpy(quat).to(self.device), cols, self._item1,
+            self._last_pos, self._last_quat, cols, self._item1,
             params=self._params(offset_to_ground), qpos_init=self._state, n_final=1)
         self._state = fin
         q = out.cpu().numpy()[0]
@@ -155,6 +171,20 @@ class GeneralMotionRetargeting:
         if not np.all(np.isfinite(q)):
             raise FloatingPointError("retarget produced non-finite qpos")
         return q.copy()
+
+    def _errors(self) -> np.ndarray:
+        if getattr(self, "_last_pos", None) is None:
+            raise RuntimeError("no targets set: call retarget() or update_targets() first")  # mink raises TargetNotSet
+        e, _, _ = self._engine.evaluate(self._state, self._last_pos, self._last_quat, self._last_cols,
+                                        offset_to_ground=self._last_offset_to_ground)
+        return e.cpu().numpy()[0]
+
+    def error1(self):
+        """|concat of the table-1 task errors| at the current configuration and targets (:188-193)."""
+        return float(self._errors()[0])
+
+    def error2(self):
+        return float(self._errors()[1])
 
     # ------------------------------------------------------------------ batched API
     def retarget_batch(self, pos, quat, body_names: Sequence[str], seq_offsets=None, chunk: int = 0, burn_in: int = 0,

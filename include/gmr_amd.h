@@ -21,6 +21,8 @@
  *                      (motion_retarget.py:117-200) and, inside it, mink.solve_ik +
  *                      Configuration.integrate_inplace (call sites motion_retarget.py:147-150,156-159,
  *                      166-169,176-179)
+ *   gmr_evaluate       error1() / error2() (motion_retarget.py:188-200) and configuration.data.xpos / xquat
+ *                      (mink.Configuration.update = mj_kinematics) at given qpos, without solving
  *   gmr_fk             KinematicsModel.forward_kinematics (kinematics_model.py:213-246)
  *   gmr_fk_min_height  the clip-global `torch.min(body_pos[..., 2])` of the height adjust
  *                      (scripts/smplx_to_robot_dataset.py:118-126)
@@ -96,6 +98,13 @@ int gmr_ik_solve(gmr_model *m, const void *human_pos, const void *human_quat, in
                  const int32_t *slot_col, int64_t n_frames, const gmr_work_item *items, int n_items,
                  const gmr_ik_params *params, const double *qpos_init, double *qpos_final, double *qpos_out,
                  int32_t *iters_out, gmr_ik_stats *stats, void *stream);
+
+/* Evaluate, per frame, the stage errors |concat_t Log(T_body^-1 T_target)| of both tables and/or the MuJoCo-convention FK.
+ *   qpos device [n][nq] f64;  human_pos/human_quat/in_dtype/n_cols/slot_col as in gmr_ik_solve (needed only with err_out)
+ *   err_out device [n][2] f64 or NULL;  xpos_out device [n][nbody][3] f64 or NULL;  xquat_out device [n][nbody][4] wxyz or NULL */
+int gmr_evaluate(gmr_model *m, const double *qpos, int64_t n_frames, const void *human_pos, const void *human_quat, int in_dtype,
+                 int n_cols, const int32_t *slot_col, int offset_to_ground, double *err_out, double *xpos_out, double *xquat_out,
+                 void *stream);
 
 /* Batched FK in the KinematicsModel convention (float32, xyzw).
  *   root_pos device [n][3], root_rot_xyzw device [n][4], dof device [n][nq-7]

@@ -186,6 +186,10 @@ def test_bad_arguments_are_rejected():
         fk_only.ik_solve(pos, quat, np.zeros(0, np.int32), make_items([0, 4]))
     out, it, _ = eng.ik_solve(pos, quat, sc, make_items([0, 0]))  # empty work: nothing written
     assert torch.isnan(out).all()
+    import ctypes
+    prm = __import__("gmr_amd._native", fromlist=["IKParams"]).IKParams()
+    rc = eng._lib.gmr_ik_solve(eng._h, None, None, 0, 14, sc.ctypes.data_as(ctypes.c_void_p), 4, None, 0, ctypes.byref(prm), None, None, None, None, None, None)
+    assert rc == -1 and b"null" in eng._lib.gmr_last_error(eng._h)  # the C ABI itself rejects null buffers
 
 
 def test_dataset_path_matches_reference_postprocessing(tmp_path):
@@ -255,3 +259,68 @@ def test_bvh_to_robot_end_to_end(golden_dir):
     cm = g._cm
     q_ref, _, _ = Oracle(cm.blob).ik_solve(gold["pos"], gold["quat"], cm.slot_columns([str(n) for n in gold["names"]]), make_items([0, len(clip)]))
     assert np.abs(q.cpu().numpy() - q_ref).max() < 1e-6
+
+
+def test_error_accessors_and_xpos_match_oracle():
+    """error1()/error2() (motion_retarget.py:188-200) and configuration.data.xpos after a retarget() call."""
+    from gmr_amd import GeneralMotionRetargeting as GMR
+    g = GMR("smplx", "engineai_pm01")
+    cm = g._cm
+    orc = Oracle(cm.blob)
+    pos, quat, names, offs, _ = synth.synth_clips(cm, 1, 4, seed=13, hard=True, dtype=np.float64)
+    with pytest.raises(RuntimeError):
+        g.error1()
+    for f in range(4):
+        q = g.retarget(_frames(pos, quat, names, f))
+    sc = cm.slot_columns(names)
+    tp, tq = orc.prepare_targets(pos[3][sc], quat[3][sc])
+    e1, _ = orc.stage_error(0, q, tp, tq, len(cm.tasks[0]))
+    e2, _ = orc.stage_error(1, q, tp, tq, len(cm.tasks[1]))
+    assert abs(g.error1() - e1) < 1e-9 and abs(g.error2() - e2) < 1e-9
+    xp, xq = orc.fk_mj(q)
+    assert np.abs(g.configuration.data.xpos - xp).max() < 1e-12
+    assert np.minimum(np.abs(g.configuration.data.xquat - xq), np.abs(g.configuration.data.xquat + xq)).max() < 1e-12
+    # batched evaluation through the engine
+    qb = g.retarget_batch(pos, quat, names)
+    err, _, _ = g._engine.evaluate(torch.from_numpy(qb).to(g.device) if isinstance(qb, np.ndarray) else qb,
+                                   torch.from_numpy(pos).to(g.device), torch.from_numpy(quat).to(g.device), sc)
+    assert err.shape == (4, 2) and abs(float(err[3, 1]) - e2) < 1e-9
+
+
+def test_five_robots_concurrently_on_streams():
+    """BASELINE config 4: heterogeneous trees side by side -- one model handle and one HIP stream per robot."""
+    from gmr_amd.engine import Engine
+    robots = ["unitree_g1", "booster_t1", "stanford_toddy", "fourier_n1", "engineai_pm01"]
+    jobs = []
+    for r in robots:
+        cm = compiled("smplx", r)
+        pos, quat, names, offs, _ = synth.synth_clips(cm, 4, 25, seed=17, hard=True, dtype=np.float32)
+        eng = Engine(cm, 0)
+        jobs.append((cm, eng, torch.from_numpy(pos).to(eng.device), torch.from_numpy(quat).to(eng.device), pos, quat, names, offs,
+                     torch.cuda.Stream(eng.device)))
+    torch.cuda.synchronize()
+    outs = []
+    for cm, eng, tp, tq, _, _, names, offs, st in jobs:
+        with torch.cuda.stream(st):
+            outs.append(eng.ik_solve(tp, tq, cm.slot_columns(names), make_items(offs))[0])
+    torch.cuda.synchronize()
+    nvps = set()
+    for (cm, eng, _, _, pos, quat, names, offs, _), q in zip(jobs, outs):
+        q_ref, _, _ = Oracle(cm.blob).ik_solve(pos, quat, cm.slot_columns(names), make_items(offs))
+        assert np.abs(q.cpu().numpy() - q_ref).max() < 1e-6
+        nvps.add(eng.info.nv_padded)
+    assert nvps == {32, 36}
+
+
+def test_degenerate_batches():
+    from gmr_amd import GeneralMotionRetargeting as GMR
+    g = GMR("smplx", "unitree_g1")
+    cm = g._cm
+    pos, quat, names, offs, _ = synth.synth_clips(cm, 1, 3, seed=1, dtype=np.float32)
+    empty = g.retarget_batch(pos[:0], quat[:0], names, seq_offsets=[0, 0])
+    assert empty.shape == (0, 36)
+    ones = g.retarget_batch(pos, quat, names, seq_offsets=[0, 1, 2, 3])  # three 1-frame clips: each starts from qpos0
+    first = g.retarget_batch(pos[:1], quat[:1], names)
+    assert np.abs(ones[0] - first[0]).max() < 1e-12
+    g2 = GMR("smplx", "unitree_g1")
+    assert np.abs(g2.retarget(_frames(pos, quat, names, 1)) - ones[1]).max() < 1e-9
