@@ -24,7 +24,7 @@ WORK_ITEM_DTYPE = np.dtype(
 assert WORK_ITEM_DTYPE.itemsize == 32
 
 EXPORTS = ["gmr_abi_version", "gmr_model_create", "gmr_model_destroy", "gmr_last_error", "gmr_model_info_get",
-           "gmr_ik_solve", "gmr_fk", "gmr_fk_min_height", "gmr_bvh_fk", "gmr_evaluate"]
+           "gmr_ik_solve", "gmr_fk", "gmr_fk_min_height", "gmr_bvh_fk", "gmr_evaluate", "gmr_smplx_keypoints"]
 
 
 class IKParams(C.Structure):
@@ -90,6 +90,8 @@ def load():
     L.gmr_fk_min_height.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp]
     L.gmr_evaluate.restype = C.c_int
     L.gmr_evaluate.argtypes = [vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp]
+    L.gmr_smplx_keypoints.restype = C.c_int
+    L.gmr_smplx_keypoints.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int64, C.c_int64, C.c_int, vp, vp, vp]
     L.gmr_bvh_fk.restype = C.c_int
     L.gmr_bvh_fk.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int64, C.c_double, vp, vp, vp]
     _lib = L

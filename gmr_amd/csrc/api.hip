@@ -18,6 +18,7 @@
 #include "bvh_kernel.hip.h"
 #include "fk_kernel.hip.h"
 #include "ik_kernel.hip.h"
+#include "smplx_kernel.hip.h"
 
 using gmr::u64;
 
@@ -594,6 +595,28 @@ int gmr_fk_min_height(gmr_model *m, const float *root_pos, const float *root_rot
   hipLaunchKernelGGL(gmr::fk_minkey_decode, dim3((n_seq + 255) / 256), dim3(256), 0, st, keys, min_z_out, n_seq);
   HIP_TRY(m, hipGetLastError());
   return GMR_OK;
+}
+
+int gmr_smplx_keypoints(const int32_t *parents, int n_joints, int joints_stride, const double *global_orient, const double *full_pose,
+                        const double *joints, int64_t n_frames, int64_t n_frames_out, int resample, double *pos_out, double *quat_out,
+                        void *stream) {
+  if (!parents || !global_orient || !full_pose || !joints || !pos_out || !quat_out || n_frames < 0 || n_frames_out < 0) return GMR_EINVAL;
+  if (n_joints < 1 || n_joints > gmr::kSmplMaxJoints || joints_stride < n_joints) return GMR_EUNSUPPORTED;
+  if (!resample && n_frames_out != n_frames) return GMR_EINVAL;
+  if (n_frames_out > 0 && n_frames == 0) return GMR_EINVAL;
+  gmr::SmplSkeleton sk{};
+  sk.n_joints = n_joints; sk.joints_stride = joints_stride; sk.resample = resample ? 1 : 0;
+  if (parents[0] != -1) return GMR_EINVAL;
+  for (int j = 0; j < n_joints; ++j) {
+    if (j > 0 && (parents[j] < 0 || parents[j] >= j)) return GMR_EINVAL;
+    sk.parent[j] = (short)parents[j];
+  }
+  if (n_frames_out == 0) return GMR_OK;
+  const int64_t nblk = (n_frames_out + 127) / 128;
+  if (nblk > 0x7fffffff) return GMR_EINVAL;
+  hipLaunchKernelGGL(gmr::smplx_keypoints_kernel, dim3((unsigned)nblk), dim3(128), 0, static_cast<hipStream_t>(stream), sk, global_orient,
+                     full_pose, joints, n_frames, n_frames_out, pos_out, quat_out);
+  return hipGetLastError() == hipSuccess ? GMR_OK : GMR_EDEVICE;
 }
 
 int gmr_bvh_fk(const int32_t *parents, int n_joints, const int32_t *euler_order, const int32_t *extra_pos_src,

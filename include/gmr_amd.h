@@ -26,6 +26,8 @@
  *   gmr_fk             KinematicsModel.forward_kinematics (kinematics_model.py:213-246)
  *   gmr_fk_min_height  the clip-global `torch.min(body_pos[..., 2])` of the height adjust
  *                      (scripts/smplx_to_robot_dataset.py:118-126)
+ *   gmr_smplx_keypoints the numeric part of get_smplx_data_offline_fast (general_motion_retargeting/utils/smpl.py:109-198)
+ *                      after the SMPL-X body model: slerp/lerp to the target frame rate, orientation chaining
  *   gmr_bvh_fk         the numeric part of load_lafan1_file (general_motion_retargeting/utils/lafan1.py:8-40):
  *                      euler_to_quat + quat_fk (utils/lafan_vendor/utils.py:56-103), Y-up -> Z-up, cm -> m,
  *                      LeftFootMod / RightFootMod synthesis
@@ -116,6 +118,15 @@ int gmr_fk(gmr_model *m, const float *root_pos, const float *root_rot_xyzw, cons
  *   seq_offsets host [n_seq+1]; min_z_out device [n_seq] float32                    */
 int gmr_fk_min_height(gmr_model *m, const float *root_pos, const float *root_rot_xyzw, const float *dof,
                       const int64_t *seq_offsets, int n_seq, float *min_z_out, void *stream);
+
+/* SMPL-X key-points (stateless): axis-angle joint rotations + joint positions -> global orientations (wxyz) and positions,
+ * optionally resampled to n_frames_out frames at times linspace(0, n_frames-1, n_frames_out).
+ *   parents host [n_joints] (parents[0] = -1, parents[j] < j);  joints_stride: joints per frame in `joints` (>= n_joints)
+ *   global_orient device [n_frames][3], full_pose device [n_frames][n_joints][3], joints device [n_frames][joints_stride][3]
+ *   pos_out device [n_frames_out][n_joints][3], quat_out device [n_frames_out][n_joints][4]                                */
+int gmr_smplx_keypoints(const int32_t *parents, int n_joints, int joints_stride, const double *global_orient, const double *full_pose,
+                        const double *joints, int64_t n_frames, int64_t n_frames_out, int resample, double *pos_out, double *quat_out,
+                        void *stream);
 
 /* BVH skeleton FK (stateless).  Joints in hierarchy order (parents[0] = -1, parents[j] < j), one Euler triple per joint.
  *   parents, euler_order[3] (0=x,1=y,2=z, the order the channels are listed), extra_*_src[n_extra]: host

@@ -324,3 +324,67 @@ def test_degenerate_batches():
     assert np.abs(ones[0] - first[0]).max() < 1e-12
     g2 = GMR("smplx", "unitree_g1")
     assert np.abs(g2.retarget(_frames(pos, quat, names, 1)) - ones[1]).max() < 1e-9
+
+
+def _smplx_restatement(global_orient, full_pose, joints, parents, src_fps, tgt_fps):
+    """scipy restatement of reference utils/smpl.py:75-198 (the module itself needs the absent smplx package)."""
+    from scipy.interpolate import interp1d
+    from scipy.spatial.transform import Rotation as R
+
+    def slerp(r1, r2, t):
+        q1, q2 = r1.as_quat(), r2.as_quat()
+        q1, q2 = q1 / np.linalg.norm(q1), q2 / np.linalg.norm(q2)
+        dot = np.sum(q1 * q2)
+        if dot < 0.0:
+            q2, dot = -q2, -dot
+        if dot > 0.9995:
+            return R.from_quat(q1 + t * (q2 - q1))
+        th0 = np.arccos(dot)
+        th = th0 * t
+        return R.from_quat((np.cos(th) - dot * np.sin(th) / np.sin(th0)) * q1 + np.sin(th) / np.sin(th0) * q2)
+
+    T, J = full_pose.shape[0], len(parents)
+    if tgt_fps < src_fps:
+        n = T // int(src_fps / tgt_fps)
+        tt = np.linspace(0, T - 1, n)
+        go, fp = [], np.zeros((n, J, 3))
+        for k, t in enumerate(tt):
+            i1 = int(np.floor(t)); i2 = min(i1 + 1, T - 1); a = t - i1
+            go.append(slerp(R.from_rotvec(global_orient[i1]), R.from_rotvec(global_orient[i2]), a).as_rotvec())
+            for j in range(J):
+                fp[k, j] = slerp(R.from_rotvec(full_pose[i1, j]), R.from_rotvec(full_pose[i2, j]), a).as_rotvec()
+        go = np.stack(go)
+        jt = np.stack([interp1d(np.arange(T), joints[:, i, c], kind="linear")(tt) for i in range(joints.shape[1]) for c in range(3)], axis=1).reshape(n, -1, 3)
+        fps = n / T * src_fps
+    else:
+        go, fp, jt, fps = global_orient, full_pose, joints, tgt_fps
+    pos, quat = np.zeros((len(go), J, 3)), np.zeros((len(go), J, 4))
+    for k in range(len(go)):
+        rots = []
+        for i in range(J):
+            rots.append(R.from_rotvec(go[k]) if i == 0 else rots[parents[i]] * R.from_rotvec(fp[k, i]))
+            pos[k, i], quat[k, i] = jt[k, i], rots[i].as_quat(scalar_first=True)
+    return pos, quat, fps
+
+
+@pytest.mark.parametrize("src_fps", [120.0, 30.0])
+def test_smplx_keypoint_adapter_matches_scipy_restatement(src_fps):
+    """parity unpinned (smplx absent): GPU adapter vs a scipy restatement of smpl.py:75-198; then straight into the IK."""
+    from gmr_amd import GeneralMotionRetargeting as GMR
+    from gmr_amd.smplx_adapter import SMPLX_JOINT_NAMES, SMPLX_PARENTS, get_smplx_data_offline_fast
+    rng = np.random.default_rng(0)
+    T = 50
+    base = rng.normal(0, 0.4, (1, 55, 3))
+    full_pose = base + np.cumsum(rng.normal(0, 0.03, (T, 55, 3)), axis=0)
+    full_pose[:, 7] = 0.0  # an exactly-zero rotation exercises the small-angle branch
+    global_orient = full_pose[:, 0].copy()
+    joints = np.cumsum(rng.normal(0, 0.01, (T, 127, 3)), axis=0) + rng.normal(0, 0.5, (1, 127, 3))
+    pos, quat, names, fps = get_smplx_data_offline_fast(global_orient, full_pose.reshape(T, -1), joints, SMPLX_PARENTS, src_fps=src_fps)
+    p_ref, q_ref, fps_ref = _smplx_restatement(global_orient, full_pose, joints, SMPLX_PARENTS, src_fps, 30.0)
+    assert names == SMPLX_JOINT_NAMES and len(names) == 55 and abs(fps - fps_ref) < 1e-12
+    assert pos.shape == p_ref.shape and np.abs(pos.cpu().numpy() - p_ref).max() < 1e-12
+    d = np.minimum(np.abs(quat.cpu().numpy() - q_ref).max(-1), np.abs(quat.cpu().numpy() + q_ref).max(-1))
+    assert d.max() < 1e-9
+    g = GMR("smplx", "unitree_g1")
+    q = g.retarget_batch(pos, quat, names)  # 55 columns, the config picks its 14
+    assert q.shape == (pos.shape[0], 36) and bool(torch.isfinite(q).all())
