@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <numeric>
@@ -39,6 +40,7 @@ struct gmr_model {
   void *ws = nullptr;
   size_t ws_bytes = 0;
   unsigned long long *dbg = nullptr;  // diagnostic builds (GMR_IK_STAMPS) only
+  bool force_generic = false;         // GMR_AMD_GENERIC_QP=1: use the dense generic QP even where the structured one applies
 };
 
 namespace {
@@ -102,7 +104,10 @@ int pick_nvp(int n_act) {
 
 template <int NVP>
 void launch_ik(const gmr_model *m, const gmr::IkLaunch &L, hipStream_t st) {
-  hipLaunchKernelGGL((gmr::ik_kernel<NVP>), dim3(L.n_items), dim3(64), m->lds_bytes, st, m->dm, L, m->lay);
+  if (m->dm.sq_ok && !m->force_generic)
+    hipLaunchKernelGGL((gmr::ik_kernel<NVP, true>), dim3(L.n_items), dim3(64), m->lds_bytes, st, m->dm, L, m->lay);
+  else
+    hipLaunchKernelGGL((gmr::ik_kernel<NVP, false>), dim3(L.n_items), dim3(64), m->lds_bytes, st, m->dm, L, m->lay);
 }
 
 int build_device_model(gmr_model *m) {
@@ -242,6 +247,88 @@ int build_device_model(gmr_model *m) {
   for (int i = 0; i < n_act; ++i)
     for (int j = 0; j < i; ++j)
       if ((aanc[i] >> j) & 1ull) hpair.push_back((unsigned short)((i << 8) | j));
+  // ---- structured QP layout ("core + limbs"): the active dofs are split into an upward-closed core C (root + trunk) and the
+  //      connected pieces left when C is removed (limbs), which never couple with one another.  Four 16-lane groups each hold
+  //      one bin of limbs (rows 0 .. 15-|C|) and a copy of the core (rows 16-|C| .. 15); see box_qp_struct in ik_kernel.hip.h.
+  std::vector<signed char> sq_gdof(64, -1), sq_owner(64, 0);
+  std::vector<int> sq_lane_of_dof(64, 0), sq_diag(64, 0);
+  std::vector<unsigned> sq_dst;
+  int sq_ok = 0, sq_nlimb = 0;
+  {
+    std::vector<int> dparent(n_act, -1), nanc(n_act, 0);
+    for (int i = 0; i < n_act; ++i) nanc[i] = __builtin_popcountll(aanc[i]);
+    for (int i = 0; i < n_act; ++i)
+      for (int j = 0; j < i; ++j)
+        if (((aanc[i] >> j) & 1ull) && (dparent[i] < 0 || nanc[j] > nanc[dparent[i]])) dparent[i] = j;
+    std::vector<char> in_core(n_act, 0);
+    for (int k = 0; k < 6; ++k) in_core[k] = 1;
+    std::vector<std::vector<int>> bins;
+    for (int guard = 0; guard < 64 && !sq_ok; ++guard) {
+      const int nc = (int)std::count(in_core.begin(), in_core.end(), (char)1);
+      if (nc > 10) break;
+      // components of the non-core dofs (dofs are indexed ancestors-first, so a parent is labelled before its children)
+      std::vector<int> comp(n_act, -1), csize, ctop;
+      for (int i = 0; i < n_act; ++i) {
+        if (in_core[i]) continue;
+        if (in_core[dparent[i]]) { comp[i] = (int)csize.size(); csize.push_back(1); ctop.push_back(i); }
+        else { comp[i] = comp[dparent[i]]; csize[comp[i]]++; }
+      }
+      const int cap = 16 - nc;
+      int worst = -1;
+      for (size_t c = 0; c < csize.size(); ++c)
+        if (csize[c] > cap && (worst < 0 || csize[c] > csize[worst])) worst = (int)c;
+      bool packed = worst < 0;
+      if (packed) {  // first-fit decreasing into <= 4 bins
+        std::vector<int> order(csize.size());
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return csize[a] > csize[b]; });
+        bins.assign(4, {});
+        std::vector<int> fill(4, 0);
+        for (int c : order) {
+          int g = 0;
+          while (g < 4 && fill[g] + csize[c] > cap) ++g;
+          if (g == 4) { packed = false; break; }
+          fill[g] += csize[c];
+          for (int i = 0; i < n_act; ++i) if (comp[i] == c) bins[g].push_back(i);
+        }
+        if (!packed) for (size_t c = 0; c < csize.size(); ++c) if (worst < 0 || csize[c] > csize[worst]) worst = (int)c;
+      }
+      if (packed) { sq_ok = 1; sq_nlimb = cap; break; }
+      in_core[ctop[worst]] = 1;  // grow the core by the top dof of the largest piece and try again
+    }
+    if (sq_ok) {
+      const int nl = sq_nlimb;
+      std::vector<int> core;
+      for (int i = 0; i < n_act; ++i) if (in_core[i]) core.push_back(i);
+      std::vector<int> grp(n_act, 0), loc(n_act, 0);
+      for (int g = 0; g < 4; ++g) {
+        std::sort(bins[g].begin(), bins[g].end());
+        for (size_t a = 0; a < bins[g].size(); ++a) {
+          const int i = bins[g][a], L = 16 * g + (int)a;
+          grp[i] = g; loc[i] = (int)a; sq_gdof[L] = (signed char)i; sq_owner[L] = 1; sq_lane_of_dof[i] = L;
+        }
+        for (size_t c = 0; c < core.size(); ++c) {
+          const int L = 16 * g + nl + (int)c;
+          sq_gdof[L] = (signed char)core[c]; sq_owner[L] = g == 0;
+          if (g == 0) { sq_lane_of_dof[core[c]] = L; loc[core[c]] = nl + (int)c; grp[core[c]] = 0; }
+        }
+      }
+      for (int i = 0; i < n_act; ++i) sq_diag[i] = loc[i] * 64 + sq_lane_of_dof[i];
+      auto hs = [](int lane, int col) { return (unsigned)(col * 64 + lane); };
+      for (unsigned short pr : hpair) {
+        const int i = pr >> 8, j = pr & 0xff;  // j above i
+        unsigned a, b;
+        if (in_core[i]) { a = hs(sq_lane_of_dof[i], loc[j]); b = hs(sq_lane_of_dof[j], loc[i]); }  // both core: group 0
+        else {
+          const int g = grp[i], Li = sq_lane_of_dof[i];
+          const int Lj = in_core[j] ? 16 * g + loc[j] : sq_lane_of_dof[j];  // the copy of the core dof inside i's group
+          if (!in_core[j] && grp[j] != g) { set_err(m, "internal: structured QP partition"); return GMR_EINVAL; }
+          a = hs(Li, loc[j]); b = hs(Lj, loc[i]);
+        }
+        sq_dst.push_back(a | (b << 16));
+      }
+    }
+  }
   // ---- composites per table: dofs sharing the same set of tasks below them share one 6x6 block ----
   std::vector<int> acomp(2 * 64, 0);
   std::vector<unsigned> compmask(2 * 2 * GMR_MAX_TASKS, 0u), comp_own(64, 0u), comp_kids(64, 0u);
@@ -329,6 +416,7 @@ int build_device_model(gmr_model *m) {
   const size_t o_abody = P.add(abody), o_akind = P.add(akind), o_aqadr = P.add(aqadr), o_alim = P.add(alim);
   const size_t o_aanc = P.add(aanc), o_arange = P.add(arange), o_acomp = P.add(acomp), o_compmask = P.add(compmask);
   const size_t o_hpair = P.add(hpair), o_fkanc = P.add(fkanc), o_cown = P.add(comp_own), o_ckids = P.add(comp_kids);
+  const size_t o_sqg = P.add(sq_gdof), o_sqo = P.add(sq_owner), o_sql = P.add(sq_lane_of_dof), o_sqd = P.add(sq_diag), o_sqdst = P.add(sq_dst);
   const size_t o_dm = P.add(std::vector<gmr::DevModel>(1));
   const size_t o_dofidx = P.add(dofidx), o_src = P.add(src_slot), o_save = P.add(save_slot);
   const size_t o_lpos = P.add(lpos), o_lrot = P.add(lrot), o_jaxis = P.add(jaxis), o_jaxis64 = P.add(jaxis64);
@@ -347,6 +435,8 @@ int build_device_model(gmr_model *m) {
   dm.abody = DP(int, o_abody); dm.akind = DP(int, o_akind); dm.aqadr = DP(int, o_aqadr); dm.alimited = DP(int, o_alim);
   dm.aanc = DP(u64, o_aanc); dm.arange = DP(double, o_arange); dm.acomp = DP(int, o_acomp); dm.compmask = DP(unsigned, o_compmask);
   dm.hpair = DP(unsigned short, o_hpair); dm.comp_own = DP(unsigned, o_cown); dm.comp_kids = DP(unsigned, o_ckids); dm.npair = (int)hpair.size(); dm.fkanc = DP(u64, o_fkanc); dm.fkrounds = fkrounds;
+  dm.sq_gdof = DP(signed char, o_sqg); dm.sq_owner = DP(signed char, o_sqo); dm.sq_lane_of_dof = DP(int, o_sql); dm.sq_diag = DP(int, o_sqd);
+  dm.sq_dst = DP(unsigned, o_sqdst); dm.sq_ok = sq_ok; dm.sq_nlimb = sq_nlimb;
   m->dm_dev = DP(gmr::DevModel, o_dm);
   gmr::FkTree &fk = m->fk;
   fk.parent = DP(int, o_parent); fk.dofidx = DP(int, o_dofidx); fk.src_slot = DP(int, o_src); fk.save_slot = DP(int, o_save);
@@ -366,27 +456,33 @@ int build_device_model(gmr_model *m) {
   L.tq = o; o += 4 * ns;
   L.S = o; o += 6 * nvp;
   L.F = o; o += 6 * nvp;
-  L.Lb = o; o += 2 * (nvp + 2);  // two broadcast rows of the Cholesky (+ a dummy slot for lanes beyond the matrix)
+  L.Lb = o; o += sq_ok && !m->force_generic ? 128 : 2 * (nvp + 2);  // broadcast rows of the factorisation (generic: 2 x (nvp+2); structured: 2 x 64)
   L.bodyc = o; o += gmr::kBodyC * nb + ((gmr::kBodyC * nb) & 1);
   L.pairs = o; o += ((int)hpair.size() + 3) / 4 + (((int)hpair.size() + 3) / 4 & 1);
+  L.V = o; o += sq_ok && !m->force_generic ? 4 * 64 : 0;  // c, lo, hi in / dq out of the structured QP, indexed by dof
   L.xpos = o; L.H = o;
   int r = o;
   r += 3 * nb + (nb & 1);
   L.xquat = r; r += 4 * nb;
   L.B = r; r += gmr::kBT * ntmax + ((gmr::kBT * ntmax) & 1);
   L.Bc = r; r += gmr::kBT * ncmax + ((gmr::kBT * ncmax) & 1);
-  o = std::max(r, o + nvp * nvp + 2);  // + a dummy slot for the unused lanes of the pair rounds
+  o = std::max(r, o + (sq_ok && !m->force_generic ? 1024 : nvp * nvp) + 2);  // structured H: 16 columns x 64 lanes  // + a dummy slot for the unused lanes of the pair rounds
   L.total_doubles = o;
   m->lds_bytes = o * (int)sizeof(double);
   m->nvp = nvp;
   m->n_act = n_act;
   if (m->lds_bytes > 160 * 1024) { set_err(m, "model needs %d bytes of LDS per wavefront", m->lds_bytes); return GMR_EUNSUPPORTED; }
   // opt in to > 64 KiB of dynamic LDS where a variant needs it
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<36>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<40>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<48>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<36, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<36, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<40, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<40, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<48, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<48, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::eval_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipGetLastError();
   return GMR_OK;
@@ -433,6 +529,7 @@ gmr_model *gmr_model_create(const void *blob, size_t blob_bytes, int device, cha
   m->h = h;
   m->blob.assign(static_cast<const uint8_t *>(blob), static_cast<const uint8_t *>(blob) + blob_bytes);
   if (hipSetDevice(device) != hipSuccess) return fail(m, "hipSetDevice failed");
+  if (const char *e = getenv("GMR_AMD_GENERIC_QP")) m->force_generic = e[0] == '1';
   if (build_device_model(m) != GMR_OK) return fail(m, "model build failed");
   return m;
 }
@@ -454,6 +551,7 @@ int gmr_model_info_get(const gmr_model *m, gmr_model_info *out) {
   out->nbody = m->h.nbody; out->nq = m->h.nq; out->nv = m->h.nv; out->nslot = m->h.nslot;
   out->ntask[0] = m->h.ntask[0]; out->ntask[1] = m->h.ntask[1];
   out->n_active_dof = m->n_act; out->nv_padded = m->nvp; out->lds_bytes = m->lds_bytes; out->device = m->device;
+  out->reserved[0] = m->dm.sq_ok && !m->force_generic ? 16 - m->dm.sq_nlimb : 0;  // core size of the structured QP, 0 = generic QP
   return GMR_OK;
 }
 

@@ -31,6 +31,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/gmr_amd.h"
 
 namespace gmr {
@@ -79,11 +81,15 @@ struct DevModel {
   const unsigned short *hpair;                  // [npair] (i << 8) | j for every dof j strictly above dof i
   const u64 *fkanc;                             // [nbody] byte r = ancestor folded in FK round r (0xff: none)
   const unsigned *comp_own, *comp_kids;         // [2][32] per composite: its own tasks / its child composites (lower ids)
-  int npair, fkrounds;
+  // structured QP (box_qp_struct): 4 groups of 16 lanes, each = one bin of limb dofs + a copy of the core dofs
+  const signed char *sq_gdof, *sq_owner;        // [64] dof of a structured lane (-1 padding); 1 if the lane owns that dof
+  const int *sq_lane_of_dof, *sq_diag;          // [64] per dof: its owner lane; LDS index of its diagonal entry
+  const unsigned *sq_dst;                       // [npair] the two LDS indices (lo/hi 16 bits) an H pair is written to
+  int npair, fkrounds, sq_ok, sq_nlimb;
 };
 
 struct LdsLayout {
-  int q, tp, tq, S, F, Lb, bodyc, pairs, xpos, xquat, B, Bc, H, total_doubles;  // H aliases [xpos, xquat, B, Bc] (dead during the QP)
+  int q, tp, tq, S, F, Lb, bodyc, pairs, V, xpos, xquat, B, Bc, H, total_doubles;  // H aliases [xpos, xquat, B, Bc] (dead during the QP)
 };
 
 struct IkLaunch {
@@ -577,8 +583,174 @@ __device__ __forceinline__ int box_qp(int lane, int n_act, const double *Hm, dou
   return it < kMaxIt ? it : -it;
 }
 
+// ------------------------------------------------------------------ structured exact box QP ("core + limbs")
+// Same problem and same active-set logic as box_qp, for models whose dofs split into an upward-closed core (root + trunk,
+// nc <= 10 dofs) and limbs that only couple through the core (every humanoid in the registry).  Lanes form four groups of 16:
+// local rows 0 .. nl-1 (nl = 16 - nc) are the dofs of the limbs binned into the group, rows nl .. 15 a copy of the core.
+// Each lane holds its row of the group's local 16 x 16 matrix [limb x limb, limb x core; core x limb, core x core]
+// (core x core and the core rhs only in group 0, zeros in the copies).  Eliminating local pivots 0 .. nl-1 in all four groups
+// at once leaves, in every copy, minus that group's Schur contribution; one cross-group sum makes every copy the full core
+// system, which all groups then factor redundantly, so back-substitution needs no further exchange.  Per step one
+// ds_write_b64 pair (column entry, rhs) and group-addressed ds_read_b128 broadcasts; LDL' without square roots; the pivot
+// lane keeps its raw row, which is what the back-substitution consumes.  16 registers per row instead of NVP.
+template <int K>
+__device__ __forceinline__ double group_bcast(double v) {  // value of lane (lane & 48) + K
+  // ds_swizzle bit mode works inside 32-lane halves: src = (lane & 0x10) | K
+  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x10 | (K << 5));
+  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x10 | (K << 5));
+  return __hiloint2double(hi, lo);
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {  // f(std::integral_constant<int, I>) for I in [I, N)
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_down(F &&f) {  // I = N-1 .. I
+  if constexpr (I < N) {
+    f(std::integral_constant<int, N - 1>{});
+    static_for_down<I, N - 1>(f);
+  }
+}
+
+__device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool pad, const double *Hs, double *Cb, double ci, double lo,
+                                             double hi, int &status, double &x_out) {
+  const int a = lane & 15;           // local row
+  const int gb = lane & 48;          // first lane of my group
+  const bool core_row = a >= nl;
+  const bool shadow = !owner && !pad;  // copy of a core dof in groups 1..3: mirrors the owner in group 0 (lane a)
+  double *Cc = Cb, *Cr = Cb + 64;
+  double x = 0.0;
+  if (owner) {
+    if (status == 1) x = lo;
+    else if (status == 2) x = hi;
+    else if (lo > 0.0) { x = lo; status = 1; }
+    else if (hi < 0.0) { x = hi; status = 2; }
+  }
+  const double gtol = 1e-10 * (1.0 + wave_max(owner ? fabs(ci) : 0.0));
+  constexpr int kMaxIt = 6 * 64 + 16;
+  int it = 0;
+  for (; it < kMaxIt; ++it) {
+    lane = launder(lane);
+    // effective status / value of every structured row (copies follow their owner, padding is pinned at 0)
+    const int st_src = __shfl(status, a);      // group 0's lane with my local index
+    const double x_src = __shfl(x, a);
+    const int st = pad ? 3 : (shadow ? st_src : status);
+    const double xe = pad ? 0.0 : (shadow ? x_src : x);
+    const bool fixed_me = st != 0;
+    const u64 fixed = __ballot(fixed_me && !pad);
+    double R[16];
+#pragma unroll
+    for (int b = 0; b < 16; b++) R[b] = Hs[b * 64 + lane];
+    double bb = (owner ? -ci : 0.0);
+    if (fixed) {  // wave-uniform: rows/columns of the working set become the identity, their values move to the rhs
+      const unsigned fg = (unsigned)(fixed >> gb) & 0xffffu;  // my group's fixed columns
+      static_for<0, 16>([&](auto B) {
+        constexpr int b = B;
+        const double xb = group_bcast<b>(xe);
+        const bool fb = (fg >> b) & 1u;
+        if (fb && !fixed_me) bb -= R[b] * xb;
+        R[b] = (fb || fixed_me) ? (b == a ? 1.0 : 0.0) : R[b];
+      });
+      if (fixed_me) bb = xe;
+    }
+    // ---- elimination of local pivot k in every group; the limb pivots first, then (after the cross-group sum) the core ----
+    double myinvd = 1.0;
+    auto step = [&](const int k) {
+      Cc[lane] = R[k];  // = H^(k)[a][k] = H^(k)[k][a]
+      Cr[lane] = bb;
+      __syncthreads();
+      const double invd = fast_rcp(Cc[gb + k]);
+      const double u = a > k ? R[k] * invd : 0.0;
+      myinvd = a == k ? invd : myinvd;
+      const double bk = Cr[gb + k];
+#pragma unroll
+      for (int jj = (k + 1) & ~1; jj < 16; jj += 2) {
+        const double2 v = *reinterpret_cast<const double2 *>(Cc + gb + jj);
+        if (jj > k) { R[jj] -= u * v.x; asm volatile("" : "+v"(R[jj])); }
+        R[jj + 1] -= u * v.y;
+        asm volatile("" : "+v"(R[jj + 1]));
+      }
+      bb -= u * bk;
+    };
+#pragma unroll
+    for (int k = 0; k < 10; k++)
+      if (k < nl) step(k);  // wave-uniform
+    // every copy of the core block / rhs <- sum over the four groups
+#pragma unroll
+    for (int b = 6; b < 16; b++) {
+      if (b >= nl) {
+        double t = R[b] + __shfl_xor(R[b], 16);
+        t += __shfl_xor(t, 32);
+        R[b] = core_row ? t : R[b];
+      }
+    }
+    {
+      double t = bb + __shfl_xor(bb, 16);
+      t += __shfl_xor(t, 32);
+      bb = core_row ? t : bb;
+    }
+#pragma unroll
+    for (int k = 6; k < 16; k++)
+      if (k >= nl) step(k);
+    // ---- back-substitution, k = 15 .. 0: x_k = (y_k - sum_{b>k} R_k[b] x_b) / d_k ----
+    static_for_down<0, 16>([&](auto K) {
+      constexpr int k = K;
+      const double xk = group_bcast<k>(bb * myinvd);
+      const double coef = a < k ? R[k] : 0.0;
+      bb -= coef * xk;
+    });
+    const double z = bb * myinvd;
+    // ratio test along x -> z over the free variables (owner lanes only)
+    double al = 2.0;
+    int side = 0;
+    const bool freev = owner && status == 0;
+    if (freev) {
+      const double d = z - x;
+      if (z > hi + 1e-14 && d > 0) { al = (hi - x) / d; side = 2; }
+      else if (z < lo - 1e-14 && d < 0) { al = (lo - x) / d; side = 1; }
+    }
+    const double amin = wave_min(al);
+    if (amin <= 1.0) {
+      const u64 who = __ballot(al == amin);
+      const int blk = (int)__builtin_ctzll(who);
+      const double ac = fmax(amin, 0.0);
+      if (freev) x += ac * (z - x);
+      if (lane == blk) { x = side == 2 ? hi : lo; status = side; }
+      continue;
+    }
+    if (freev) x = z;
+    const u64 fixed_own = __ballot(owner && status != 0);
+    if (!fixed_own) { ++it; break; }
+    // multipliers of the working set: g_j = c_j + (H x)_j.  (H x) per structured row with the converged x of every column,
+    // then the four copies of a core row are summed (limb rows are complete inside their group).
+    double hx = 0.0;
+    {
+      const double x_src2 = __shfl(x, a);
+      const double xe2 = pad ? 0.0 : (shadow ? x_src2 : x);
+      static_for<0, 16>([&](auto B) {
+        constexpr int b = B;
+        hx += Hs[b * 64 + lane] * group_bcast<b>(xe2);
+      });
+      double t = hx + __shfl_xor(hx, 16);
+      t += __shfl_xor(t, 32);
+      hx = core_row ? t : hx;
+    }
+    const double g = ci + hx;
+    const double viol = (owner && status != 0) ? (status == 1 ? -g : g) : -INFINITY;
+    const double worst = wave_max(viol);
+    if (!(worst > gtol)) { ++it; break; }
+    const u64 whr = __ballot(viol == worst);
+    if (lane == (int)__builtin_ctzll(whr)) status = 0;
+  }
+  x_out = x;
+  return it < kMaxIt ? it : -it;
+}
+
 // ------------------------------------------------------------------ the kernel
-template <int NVP>
+template <int NVP, bool SQ>
 __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const DevModel m, IkLaunch L, LdsLayout lay) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
@@ -611,6 +783,12 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
     bcst[10] = __longlong_as_double((long long)((m.fkanc[lane] & 0x0000ffffffffffffull) | ((u64)(m.jtype[lane] & 0xff) << 48) | ((u64)(m.qadr[lane] & 0xff) << 56)));
   }
   for (int i = lane; i < npair; i += 64) pairs[i] = m.hpair[i];
+  // structured QP: this lane's row in the 4 x 16 layout
+  const int sq_g = SQ ? (int)m.sq_gdof[lane] : -1;
+  const bool sq_own = SQ ? m.sq_owner[lane] != 0 : false, sq_pad = sq_g < 0;
+  const int sq_mydiag = SQ && real_row ? m.sq_diag[lane] : 0;
+  double *V = lds + lay.V;
+  int sq_status = 0;
   for (int i = lane; i < nq; i += 64) q[i] = w.init_row >= 0 ? L.qinit[(size_t)w.init_row * nq + i] : m.qpos0[i];
   int status = real_row ? 0 : 3;
   __syncthreads();
@@ -770,31 +948,72 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         }
         __syncthreads();  // Bc / poses are dead from here: H overwrites them
         GMR_STAMP(6);
-        // ---- H (dense, symmetric) into LDS: zero fill, then the structurally non-zero pairs spread over all lanes ----
-        for (int idx = lane; idx < NVP * NVP; idx += 64) Hm[idx] = 0.0;  // same wave: LDS keeps program order, no barrier needed
-        {
-          int prs[kPairRounds];
+        // ---- H into LDS: zero fill, then the structurally non-zero pairs spread over all lanes ----
+        double dq;
+        int qit;
+        if constexpr (SQ) {
+          // structured layout Hs[col * 64 + lane]: every pair lands in the (at most two) rows that carry it
+          for (int idx = lane; idx < 1024; idx += 64) Hm[idx] = 0.0;  // same wave: LDS keeps program order, no barrier needed
+          {
+            int prs[kPairRounds];
+            unsigned dst[kPairRounds];
 #pragma unroll
-          for (int r = 0; r < kPairRounds; r++) prs[r] = lane + 64 * r < npair ? (int)pairs[launder(lane + 64 * r)] : -1;
+            for (int r = 0; r < kPairRounds; r++) {
+              const int pi = launder(lane + 64 * r);
+              prs[r] = pi < npair ? (int)pairs[pi] : -1;
+              dst[r] = pi < npair ? m.sq_dst[pi] : 0u;
+            }
 #pragma unroll
-          for (int r = 0; r < kPairRounds; r++) {  // H[i][j] = S_j . F_i for every dof j above i (and the mirror)
-            if (64 * r < npair) {  // wave-uniform
-              const int pr = prs[r], i = pr >= 0 ? pr >> 8 : 0, j = pr >= 0 ? pr & 0xff : 0;
-              const double *Sj = S + 6 * j, *Fi = F + 6 * i;
-              const double d = Sj[0] * Fi[0] + Sj[1] * Fi[1] + Sj[2] * Fi[2] + Sj[3] * Fi[3] + Sj[4] * Fi[4] + Sj[5] * Fi[5];
-              Hm[pr >= 0 ? j * NVP + i : NVP * NVP] = d;       // unused lanes hit the dummy slot
-              Hm[pr >= 0 ? i * NVP + j : NVP * NVP + 1] = d;
+            for (int r = 0; r < kPairRounds; r++) {
+              if (64 * r < npair) {  // wave-uniform
+                const int pr = prs[r], i = pr >= 0 ? pr >> 8 : 0, j = pr >= 0 ? pr & 0xff : 0;
+                const double *Sj = S + 6 * j, *Fi = F + 6 * i;
+                const double d = Sj[0] * Fi[0] + Sj[1] * Fi[1] + Sj[2] * Fi[2] + Sj[3] * Fi[3] + Sj[4] * Fi[4] + Sj[5] * Fi[5];
+                Hm[pr >= 0 ? (int)(dst[r] & 0xffffu) : 1024] = d;  // unused lanes hit the dummy slot
+                Hm[pr >= 0 ? (int)(dst[r] >> 16) : 1025] = d;
+              }
             }
           }
+          if (real_row) {
+            const double *Fi = F + 6 * lane;
+            Hm[sq_mydiag] = Si[0] * Fi[0] + Si[1] * Fi[1] + Si[2] * Fi[2] + Si[3] * Fi[3] + Si[4] * Fi[4] + Si[5] * Fi[5] + diag;
+            V[lane] = ci; V[64 + lane] = lo; V[128 + lane] = hi;
+          }
+          if (sq_pad) Hm[(lane & 15) * 64 + lane] = 1.0;
+          __syncthreads();
+          GMR_STAMP(7);
+          const int gi = sq_own ? sq_g : 0;
+          const double s_ci = sq_own ? V[gi] : 0.0, s_lo = sq_own ? V[64 + gi] : -1e30, s_hi = sq_own ? V[128 + gi] : 1e30;
+          double xs;
+          qit = box_qp_struct(lane, m.sq_nlimb, sq_own, sq_pad, Hm, lds + lay.Lb, s_ci, s_lo, s_hi, sq_status, xs);
+          if (sq_own) V[192 + sq_g] = xs;
+          __syncthreads();
+          dq = real_row ? V[192 + lane] : 0.0;
+        } else {
+          for (int idx = lane; idx < NVP * NVP; idx += 64) Hm[idx] = 0.0;  // same wave: LDS keeps program order, no barrier needed
+          {
+            int prs[kPairRounds];
+#pragma unroll
+            for (int r = 0; r < kPairRounds; r++) prs[r] = lane + 64 * r < npair ? (int)pairs[launder(lane + 64 * r)] : -1;
+#pragma unroll
+            for (int r = 0; r < kPairRounds; r++) {  // H[i][j] = S_j . F_i for every dof j above i (and the mirror)
+              if (64 * r < npair) {  // wave-uniform
+                const int pr = prs[r], i = pr >= 0 ? pr >> 8 : 0, j = pr >= 0 ? pr & 0xff : 0;
+                const double *Sj = S + 6 * j, *Fi = F + 6 * i;
+                const double d = Sj[0] * Fi[0] + Sj[1] * Fi[1] + Sj[2] * Fi[2] + Sj[3] * Fi[3] + Sj[4] * Fi[4] + Sj[5] * Fi[5];
+                Hm[pr >= 0 ? j * NVP + i : NVP * NVP] = d;       // unused lanes hit the dummy slot
+                Hm[pr >= 0 ? i * NVP + j : NVP * NVP + 1] = d;
+              }
+            }
+          }
+          if (lane < NVP) {
+            const double *Fi = F + 6 * lane;
+            Hm[lane * NVP + lane] = real_row ? Si[0] * Fi[0] + Si[1] * Fi[1] + Si[2] * Fi[2] + Si[3] * Fi[3] + Si[4] * Fi[4] + Si[5] * Fi[5] + diag : 1.0;
+          }
+          __syncthreads();
+          GMR_STAMP(7);
+          qit = box_qp<NVP>(lane, n_act, Hm, lds + lay.Lb, ci, lo, hi, status, dq);
         }
-        if (lane < NVP) {
-          const double *Fi = F + 6 * lane;
-          Hm[lane * NVP + lane] = real_row ? Si[0] * Fi[0] + Si[1] * Fi[1] + Si[2] * Fi[2] + Si[3] * Fi[3] + Si[4] * Fi[4] + Si[5] * Fi[5] + diag : 1.0;
-        }
-        __syncthreads();
-        GMR_STAMP(7);
-        double dq;
-        const int qit = box_qp<NVP>(lane, n_act, Hm, lds + lay.Lb, ci, lo, hi, status, dq);
         if (qit < 0) qpflag = 1;
         GMR_STAMP(8);
 #ifdef GMR_IK_STAMPS
