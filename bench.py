@@ -75,9 +75,9 @@ def host_cores() -> int:
     return max(1, n)
 
 
-# HBM bytes per output frame of ik_kernel measured with rocprofv3 PMC passes (profiles/r01_v2_pmc_*: 2 x FETCH_SIZE
-# (gfx950 counts half, MI355X_MICROARCH.md "HBM") + WRITE_SIZE over a 1.2288e6-frame launch): 486 + 364 MB.
-MEASURED_TRAFFIC_BYTES_PER_FRAME = (2 * 237367.0 * 1024 + 355521.0 * 1024) / 1228800.0
+# HBM bytes per output frame of ik_kernel measured with rocprofv3 PMC passes (profiles/r01_v3_pmc_*: 2 x FETCH_SIZE
+# (gfx950 counts half, MI355X_MICROARCH.md "HBM") + WRITE_SIZE over a 1.2288e6-frame launch): 487 + 363 MB.
+MEASURED_TRAFFIC_BYTES_PER_FRAME = (2 * 237568.6 * 1024 + 354496.8 * 1024) / 1228800.0
 
 
 def bytes_per_frame(cm, in_itemsize=4) -> int:
@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic clips generated, tiled to --clips")
     ap.add_argument("--cpu-clips", type=int, default=0, help="clips solved by the CPU oracle (baseline + parity); 0 = 2 per host core, capped at 512")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--hot-only", action="store_true", help="only the warmup + timed launches (no single-clip / CPU legs): the "
+                    "form profiled under rocprofv3 so the kernel's average duration is that of the timed launch")
     args = ap.parse_args()
 
     rank, world, local = gdist.init_from_env()
@@ -177,12 +179,12 @@ def main():
                 "clips_per_gpu": S, "frames_per_clip": T, "frames_per_step": n_frames * world, "parallelism": f"clip-sharded x{world}",
             },
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
-                         "traffic": MEASURED_TRAFFIC_BYTES_PER_FRAME * n_frames, "traffic_source": "profiles/r01_v2_pmc_* scaled to this launch", "kernel": "gmr::ik_kernel<36>", "kernel_ms": kern_ms, "bytes_per_frame": bpf},
+                         "traffic": MEASURED_TRAFFIC_BYTES_PER_FRAME * n_frames, "traffic_source": "profiles/r01_v3_pmc_* scaled to this launch", "kernel": "gmr::ik_kernel<36, true>", "kernel_ms": kern_ms, "bytes_per_frame": bpf},
             "valu": {"bound": "fp64-vector", "achieved": ach_tf, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": ach_tf / FP64_VECTOR_PEAK_TF,
                      "flop_per_solve": fsolve, "mean_solves_per_frame": mean_solves},
             "qp_iteration_caps_hit": qp_capped,
         }
-        if world == 1:
+        if world == 1 and not args.hot_only:
             # BASELINE config 2 taken literally: ONE 3000-frame clip on one GPU, parallel-in-time chunks with verified
             # boundaries (Engine.ik_solve_chunked) vs the same clip solved sequentially by one wavefront.
             one_p, one_q, one_offs = pos[:T].contiguous(), quat[:T].contiguous(), offs[:2]
@@ -202,7 +204,7 @@ def main():
                 "chunk": 8, "burn_in": 24, "passes": info["passes"], "resolved_frames": info["resolved_frames"],
                 "max_abs_diff_vs_sequential": float((q_chk - q_seq).abs().max().item()), "includes": "host scheduling + verification passes",
             }
-        if world == 1 and not args.no_cpu:
+        if world == 1 and not args.no_cpu and not args.hot_only:
             from oracle.oracle import Oracle  # checker / comparator only
             orc = Oracle(cm.blob)
             cores = host_cores()

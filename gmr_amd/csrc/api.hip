@@ -447,26 +447,26 @@ int build_device_model(gmr_model *m) {
   HIP_TRY(m, hipMemcpy(m->dev, P.buf.data(), P.buf.size(), hipMemcpyHostToDevice));
   m->fk_lds_bytes = std::max(1, nslots) * 7 * gmr::kFkThreads * (int)sizeof(float);
 
-  // ---- LDS layout of the IK kernel (doubles) ----
+  // ---- LDS layout of the IK kernel (doubles).  Lifetimes inside one solve:
+  //   poses (FK .. screws) | Bt (task blocks .. composites) | Bc (composites .. F)   -> Bc overwrites the dead poses
+  //   S, F (screws / F .. H assembly)                                                 -> the factorisation's broadcast rows Lb overwrite S
+  //   H (H assembly .. QP) overwrites [Bt | poses/Bc];  V (structured QP only): c in / dq out, per dof
   const int ntmax = std::max(h.ntask[0], h.ntask[1]), ncmax = std::max(ncomp[0], ncomp[1]);
+  const bool sq = sq_ok && !m->force_generic;
   gmr::LdsLayout &L = m->lay;
+  auto even = [](int x) { return (x + 1) & ~1; };
   int o = 0;
-  L.q = o; o += (nq + 1) & ~1;
-  L.tp = o; o += 3 * ns + (ns & 1);
+  L.q = o; o += even(nq);
+  L.tp = o; o += even(3 * ns);
   L.tq = o; o += 4 * ns;
-  L.S = o; o += 6 * nvp;
+  L.V = o; o += sq ? even(n_act) : 0;
+  L.bodyc = GMR_IK_STAGE_TREE ? o : -1; o += GMR_IK_STAGE_TREE ? even(gmr::kBodyC * nb) : 0;
+  L.S = o; L.Lb = o; o += std::max(6 * nvp, sq ? 128 : 2 * (nvp + 2));
   L.F = o; o += 6 * nvp;
-  L.Lb = o; o += sq_ok && !m->force_generic ? 128 : 2 * (nvp + 2);  // broadcast rows of the factorisation (generic: 2 x (nvp+2); structured: 2 x 64)
-  L.bodyc = o; o += gmr::kBodyC * nb + ((gmr::kBodyC * nb) & 1);
-  L.pairs = o; o += ((int)hpair.size() + 3) / 4 + (((int)hpair.size() + 3) / 4 & 1);
-  L.V = o; o += sq_ok && !m->force_generic ? 4 * 64 : 0;  // c, lo, hi in / dq out of the structured QP, indexed by dof
-  L.xpos = o; L.H = o;
-  int r = o;
-  r += 3 * nb + (nb & 1);
-  L.xquat = r; r += 4 * nb;
-  L.B = r; r += gmr::kBT * ntmax + ((gmr::kBT * ntmax) & 1);
-  L.Bc = r; r += gmr::kBT * ncmax + ((gmr::kBT * ncmax) & 1);
-  o = std::max(r, o + (sq_ok && !m->force_generic ? 1024 : nvp * nvp) + 2);  // structured H: 16 columns x 64 lanes  // + a dummy slot for the unused lanes of the pair rounds
+  L.B = o; L.H = o;
+  const int bt = even(gmr::kBT * ntmax), px = std::max(even(7 * nb), even(gmr::kBT * ncmax));
+  L.xpos = o + bt; L.xquat = L.xpos + even(3 * nb); L.Bc = o + bt;
+  o += std::max(bt + px, (sq ? 1024 : nvp * nvp) + 2);  // + a dummy slot for the unused lanes of the pair rounds
   L.total_doubles = o;
   m->lds_bytes = o * (int)sizeof(double);
   m->nvp = nvp;

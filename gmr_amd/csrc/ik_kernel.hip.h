@@ -51,6 +51,9 @@ typedef unsigned long long u64;
 #ifndef GMR_QP_GROUP
 #define GMR_QP_GROUP 6
 #endif
+#ifndef GMR_IK_STAGE_TREE
+#define GMR_IK_STAGE_TREE 1  // joint tree staged in LDS per wavefront; 0 = re-read from L2 (saves 3.3 KB LDS for G1)
+#endif
 #ifndef GMR_IK_WAVES_PER_SIMD
 #define GMR_IK_WAVES_PER_SIMD 2
 #endif
@@ -89,7 +92,7 @@ struct DevModel {
 };
 
 struct LdsLayout {
-  int q, tp, tq, S, F, Lb, bodyc, pairs, V, xpos, xquat, B, Bc, H, total_doubles;  // H aliases [xpos, xquat, B, Bc] (dead during the QP)
+  int q, tp, tq, S, F, Lb, V, bodyc, xpos, xquat, B, Bc, H, total_doubles;  // H aliases [xpos, xquat, B, Bc] (dead during the QP)
 };
 
 struct IkLaunch {
@@ -261,16 +264,43 @@ __device__ __forceinline__ void qrot(const double q[4], const double v[3], doubl
   o[2] = v[2] + q[0] * tz + (q[1] * ty - q[2] * tx);
 }
 constexpr int kBodyC = 11;  // doubles per body in the LDS-staged joint tree: pos(3) quat(4) axis(3) {fkanc(6 bytes), jtype, qadr}
-__device__ __forceinline__ void fk_phase(const double *bodyc, int nbody, int nrounds, int lane, const double *q, double *xpos,
-                                         double *xquat) {
+// Stage this lane's body of the joint tree into LDS (once per wavefront).
+__device__ __forceinline__ void stage_tree(const DevModel &m, int lane, double *bodyc) {
+  if (lane < m.nbody) {
+    double *bcst = bodyc + kBodyC * lane;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { bcst[i] = m.bpos[3 * lane + i]; bcst[7 + i] = m.axis[3 * lane + i]; }
+#pragma unroll
+    for (int i = 0; i < 4; i++) bcst[3 + i] = m.bquat[4 * lane + i];
+    bcst[10] = __longlong_as_double((long long)((m.fkanc[lane] & 0x0000ffffffffffffull) | ((u64)(m.jtype[lane] & 0xff) << 48) | ((u64)(m.qadr[lane] & 0xff) << 56)));
+  }
+}
+// bodyc != nullptr: joint tree staged in LDS (default).  nullptr: re-read from the L2-resident model each call -- the
+// variant for builds that trade LDS for occupancy (GMR_IK_STAGE_TREE=0).
+__device__ __forceinline__ void fk_phase(const DevModel &m, const double *bodyc, int nbody, int nrounds, int lane, const double *q,
+                                         double *xpos, double *xquat) {
   const bool has = lane < nbody;
-  const double *bcst = bodyc + kBodyC * (has ? lane : 0);
-  const u64 packed = (u64)__double_as_longlong(bcst[10]);
-  const int jtype = (int)((packed >> 48) & 0xff), qadr = (int)(packed >> 56);
-  const u64 ancs = has ? (packed | 0xffff000000000000ull) : ~0ull;
-  double pos[3] = {bcst[0], bcst[1], bcst[2]};
-  const double bq[4] = {bcst[3], bcst[4], bcst[5], bcst[6]};
-  const double ax[3] = {bcst[7], bcst[8], bcst[9]};
+  int jtype, qadr;
+  u64 ancs;
+  double pos[3], bq[4], ax[3];
+  if (bodyc) {
+    const double *bcst = bodyc + kBodyC * (has ? lane : 0);
+    const u64 packed = (u64)__double_as_longlong(bcst[10]);
+    jtype = (int)((packed >> 48) & 0xff); qadr = (int)(packed >> 56);
+    ancs = has ? (packed | 0xffff000000000000ull) : ~0ull;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { pos[i] = bcst[i]; ax[i] = bcst[7 + i]; }
+#pragma unroll
+    for (int i = 0; i < 4; i++) bq[i] = bcst[3 + i];
+  } else {
+    const int b = launder(has ? lane : 0);
+    jtype = m.jtype[b]; qadr = m.qadr[b];
+    ancs = has ? m.fkanc[b] : ~0ull;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { pos[i] = m.bpos[3 * b + i]; ax[i] = m.axis[3 * b + i]; }
+#pragma unroll
+    for (int i = 0; i < 4; i++) bq[i] = m.bquat[4 * b + i];
+  }
   double ql[4] = {bq[0], bq[1], bq[2], bq[3]};
   if (jtype == GMR_JNT_FREE) {
     ql[0] = q[3]; ql[1] = q[4]; ql[2] = q[5]; ql[3] = q[6];
@@ -756,8 +786,9 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
   const int lane = threadIdx.x;
   double *q = lds + lay.q, *xpos = lds + lay.xpos, *xquat = lds + lay.xquat, *tp = lds + lay.tp, *tq = lds + lay.tq;
   double *Bt = lds + lay.B, *Bc = lds + lay.Bc, *S = lds + lay.S, *F = lds + lay.F, *Hm = lds + lay.H;
-  double *bodyc = lds + lay.bodyc;
-  unsigned short *pairs = reinterpret_cast<unsigned short *>(lds + lay.pairs);
+  const unsigned short *pairs = m.hpair;  // read through L2 each solve (laundered index)
+  double *bodyc = lay.bodyc >= 0 ? lds + lay.bodyc : nullptr;
+  if (bodyc) stage_tree(m, lane, bodyc);
   const gmr_work_item w = L.items[blockIdx.x];
   const gmr_ik_params prm = L.prm;
 #ifdef GMR_IK_STAMPS
@@ -773,16 +804,6 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
   const int s_col = L.slot_col[is_slot ? lane : 0], root_col = L.slot_col[root_slot];
   constexpr int kPairRounds = (NVP * (NVP - 1) / 2 + 63) / 64;
 
-  // ---- stage the joint tree and the H pair list in LDS (read every solve) ----
-  if (lane < nbody) {
-    double *bcst = bodyc + kBodyC * lane;
-#pragma unroll
-    for (int i = 0; i < 3; i++) { bcst[i] = m.bpos[3 * lane + i]; bcst[7 + i] = m.axis[3 * lane + i]; }
-#pragma unroll
-    for (int i = 0; i < 4; i++) bcst[3 + i] = m.bquat[4 * lane + i];
-    bcst[10] = __longlong_as_double((long long)((m.fkanc[lane] & 0x0000ffffffffffffull) | ((u64)(m.jtype[lane] & 0xff) << 48) | ((u64)(m.qadr[lane] & 0xff) << 56)));
-  }
-  for (int i = lane; i < npair; i += 64) pairs[i] = m.hpair[i];
   // structured QP: this lane's row in the 4 x 16 layout
   const int sq_g = SQ ? (int)m.sq_gdof[lane] : -1;
   const bool sq_own = SQ ? m.sq_owner[lane] != 0 : false, sq_pad = sq_g < 0;
@@ -868,7 +889,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
       const int ncomp = m.ncomp[tab];
 
       double e[6] = {0, 0, 0, 0, 0, 0}, sh = 0.0, ch = 1.0;
-      fk_phase(bodyc, nbody, fkrounds, lane, q, xpos, xquat);
+      fk_phase(m, bodyc, nbody, fkrounds, lane, q, xpos, xquat);
       GMR_STAMP(1);
       double curr = fast_sqrt(wave_sum(is_task ? task_residual(t_body, t_slot, xpos, xquat, tp, tq, e, sh, ch) : 0.0));
       GMR_STAMP(2);
@@ -939,7 +960,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
 #pragma unroll
           for (int k = 0; k < 6; k++) F[6 * lane + k] = Fi[k];
           ci = Si[0] * B[21] + Si[1] * B[22] + Si[2] * B[23] + Si[3] * B[24] + Si[4] * B[25] + Si[5] * B[26];
-          if (a_lim) {  // mink ConfigurationLimit: -gain (q - lower) <= dq <= gain (upper - q)
+          if (!SQ && a_lim) {  // mink ConfigurationLimit: -gain (q - lower) <= dq <= gain (upper - q)
             const double qv = q[a_qadr];
             const int ar = launder(2 * lane);
             lo = -prm.limit_gain * (qv - m.arange[ar]);
@@ -977,18 +998,25 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
           if (real_row) {
             const double *Fi = F + 6 * lane;
             Hm[sq_mydiag] = Si[0] * Fi[0] + Si[1] * Fi[1] + Si[2] * Fi[2] + Si[3] * Fi[3] + Si[4] * Fi[4] + Si[5] * Fi[5] + diag;
-            V[lane] = ci; V[64 + lane] = lo; V[128 + lane] = hi;
+            V[lane] = ci;
           }
           if (sq_pad) Hm[(lane & 15) * 64 + lane] = 1.0;
           __syncthreads();
           GMR_STAMP(7);
-          const int gi = sq_own ? sq_g : 0;
-          const double s_ci = sq_own ? V[gi] : 0.0, s_lo = sq_own ? V[64 + gi] : -1e30, s_hi = sq_own ? V[128 + gi] : 1e30;
+          const int gi = launder(sq_own ? sq_g : 0);
+          const double s_ci = sq_own ? V[gi] : 0.0;
+          double s_lo = -1e30, s_hi = 1e30;
+          if (sq_own && m.alimited[gi]) {  // mink ConfigurationLimit, evaluated by the lane that owns the dof in the QP layout
+            const double qv = q[m.aqadr[gi]];
+            s_lo = -prm.limit_gain * (qv - m.arange[2 * gi]);
+            s_hi = prm.limit_gain * (m.arange[2 * gi + 1] - qv);
+          }
           double xs;
           qit = box_qp_struct(lane, m.sq_nlimb, sq_own, sq_pad, Hm, lds + lay.Lb, s_ci, s_lo, s_hi, sq_status, xs);
-          if (sq_own) V[192 + sq_g] = xs;
           __syncthreads();
-          dq = real_row ? V[192 + lane] : 0.0;
+          if (sq_own) V[sq_g] = xs;  // c is dead: the same array carries dq back to the dof-indexed lanes
+          __syncthreads();
+          dq = real_row ? V[lane] : 0.0;
         } else {
           for (int idx = lane; idx < NVP * NVP; idx += 64) Hm[idx] = 0.0;  // same wave: LDS keeps program order, no barrier needed
           {
@@ -1044,7 +1072,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         __syncthreads();
         GMR_STAMP(9);
         ++solves;
-        fk_phase(bodyc, nbody, fkrounds, lane, q, xpos, xquat);
+        fk_phase(m, bodyc, nbody, fkrounds, lane, q, xpos, xquat);
         GMR_STAMP(1);
         const double next = fast_sqrt(wave_sum(is_task ? task_residual(t_body, t_slot, xpos, xquat, tp, tq, e, sh, ch) : 0.0));
         GMR_STAMP(2);
@@ -1087,19 +1115,10 @@ __global__ void __launch_bounds__(64) eval_kernel(const DevModel m, EvalLaunch L
   const int lane = threadIdx.x;
   const long long f = blockIdx.x;
   double *q = lds + lay.q, *xpos = lds + lay.xpos, *xquat = lds + lay.xquat, *tp = lds + lay.tp, *tq = lds + lay.tq;
-  double *bodyc = lds + lay.bodyc;
   const int nq = m.nq, nbody = m.nbody, nslot = m.nslot, root_slot = m.root_slot;
-  if (lane < nbody) {
-    double *bcst = bodyc + kBodyC * lane;
-#pragma unroll
-    for (int i = 0; i < 3; i++) { bcst[i] = m.bpos[3 * lane + i]; bcst[7 + i] = m.axis[3 * lane + i]; }
-#pragma unroll
-    for (int i = 0; i < 4; i++) bcst[3 + i] = m.bquat[4 * lane + i];
-    bcst[10] = __longlong_as_double((long long)((m.fkanc[lane] & 0x0000ffffffffffffull) | ((u64)(m.jtype[lane] & 0xff) << 48) | ((u64)(m.qadr[lane] & 0xff) << 56)));
-  }
   for (int i = lane; i < nq; i += 64) q[i] = L.qpos[(size_t)f * nq + i];
   __syncthreads();
-  fk_phase(bodyc, nbody, m.fkrounds, lane, q, xpos, xquat);
+  fk_phase(m, nullptr, nbody, m.fkrounds, lane, q, xpos, xquat);
   if (L.xpos_out)
     for (int i = lane; i < 3 * nbody; i += 64) L.xpos_out[(size_t)f * 3 * nbody + i] = xpos[i];
   if (L.xquat_out)
