@@ -155,6 +155,7 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     it = (iters & 0x3FFFFFFF).to(torch.float64)
     mean_solves = float(it.mean().item())
+    solves_hist = torch.bincount((iters & 0x3FFFFFFF).flatten().to(torch.int64), minlength=23)[:23].cpu().tolist()
     qp_capped = int((iters >> 30).sum().item())
     if torch.isnan(out).any().item():
         raise SystemExit("non-finite qpos in the benchmark output")
@@ -181,7 +182,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
                          "traffic": MEASURED_TRAFFIC_BYTES_PER_FRAME * n_frames, "traffic_source": "profiles/r01_v3_pmc_* scaled to this launch", "kernel": "gmr::ik_kernel<36, true>", "kernel_ms": kern_ms, "bytes_per_frame": bpf},
             "valu": {"bound": "fp64-vector", "achieved": ach_tf, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": ach_tf / FP64_VECTOR_PEAK_TF,
-                     "flop_per_solve": fsolve, "mean_solves_per_frame": mean_solves},
+                     "flop_per_solve": fsolve, "mean_solves_per_frame": mean_solves,
+                     "solves_per_frame_histogram": solves_hist},
             "qp_iteration_caps_hit": qp_capped,
         }
         if world == 1 and not args.hot_only:
@@ -199,6 +201,18 @@ def main():
                 return float(np.median(ts)), r
             t_seq, (q_seq, _, _) = timed(lambda: eng.ik_solve(one_p, one_q, sc, make_items(one_offs)), reps=3)
             t_chk, (q_chk, _, info) = timed(lambda: eng.ik_solve_chunked(one_p, one_q, sc, one_offs, chunk=8, burn_in=24))
+            # live single-sequence mode (gmr_session_*): host frame in -> host qpos out, one launch per frame
+            ses = eng.session(sc, int(one_p.shape[1]), dtype=np.float32)
+            hp, hq = one_p[:256].cpu().numpy(), one_q[:256].cpu().numpy()
+            lat = []
+            for i in range(256):
+                t1 = time.perf_counter()
+                ses.step(hp[i], hq[i])
+                lat.append(time.perf_counter() - t1)
+            ses.close()
+            lat = np.array(lat[16:]) * 1e6
+            result["live_session"] = {"frames": int(lat.size), "median_latency_us": float(np.median(lat)), "p99_latency_us": float(np.quantile(lat, 0.99)),
+                                      "frames_per_s": float(1e6 / lat.mean()), "includes": "host staging + launch + kernel + sync, one wavefront"}
             result["single_clip"] = {
                 "frames": T, "sequential_frames_per_s": T / t_seq, "verified_chunked_frames_per_s": T / t_chk,
                 "chunk": 8, "burn_in": 24, "passes": info["passes"], "resolved_frames": info["resolved_frames"],
@@ -227,8 +241,15 @@ def main():
                 "single_core_value": one * T / t_one, "single_core_sample": f"{one} clip(s) x {T} frames",
                 "reference_published": "35-70 frames/s single Python process (README.md:617-620, other hardware, config unstated)",
             }
+            # root rotation error as the geodesic angle between the two unit quaternions
+            dots = np.abs(np.sum(q_gpu[:, 3:7] * q_ref[:, 3:7], axis=1)) / (
+                np.linalg.norm(q_gpu[:, 3:7], axis=1) * np.linalg.norm(q_ref[:, 3:7], axis=1))
+            geo = 2.0 * np.arccos(np.clip(dots, 0.0, 1.0))
             result["parity"] = {
                 "max_abs_qpos_err_vs_cpu": float(d.max()), "max_abs_hinge_err_rad": float(d[:, 7:].max()),
+                "p999_abs_hinge_err_rad": float(np.quantile(d[:, 7:].max(axis=1), 0.999)),
+                "max_root_pos_err_m": float(np.linalg.norm(q_gpu[:, :3] - q_ref[:, :3], axis=1).max()),
+                "max_root_geodesic_err_rad": float(geo.max()),
                 "frames_compared": int(nc * T), "frames_with_different_solve_count": int((it_gpu != it_ref).sum()),
                 "tolerance_target_rad": 1e-3,
             }

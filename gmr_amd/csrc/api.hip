@@ -43,6 +43,16 @@ struct gmr_model {
   bool force_generic = false;         // GMR_AMD_GENERIC_QP=1: use the dense generic QP even where the structured one applies
 };
 
+// State of a single-sequence session (gmr_session_*): one frame per call, warm start carried on the device.
+struct gmr_session {
+  gmr_model *m = nullptr;
+  hipStream_t st = nullptr;
+  uint8_t *host = nullptr;   // pinned, device-visible: [pos | quat | qpos_out(nq) | solves]
+  uint8_t *dev = nullptr;    // [qpos state (nq doubles) | work item | slot_col]
+  size_t pos_bytes = 0, quat_bytes = 0, quat_off = 0, out_off = 0;
+  gmr::IkLaunch L{};
+};
+
 namespace {
 
 void set_err(gmr_model *m, const char *fmt, ...) {
@@ -95,10 +105,18 @@ int ensure_ws(gmr_model *m, size_t bytes) {
   return GMR_OK;
 }
 
+// Kernel variants by padded system size.  GMR_IK_DEV_ONLY36 (experiments only, never the shipped library) builds just
+// ik_kernel<36, true> to cut compile time.
+#ifdef GMR_IK_DEV_ONLY36
+#define GMR_FOR_EACH_NVP(X) X(36)
+#else
+#define GMR_FOR_EACH_NVP(X) X(32) X(36) X(40) X(48) X(64)
+#endif
+
 int pick_nvp(int n_act) {
-  const int variants[] = {32, 36, 40, 48, 64};
-  for (int v : variants)
-    if (n_act <= v) return v;
+#define GMR_X(v) if (n_act <= v) return v;
+  GMR_FOR_EACH_NVP(GMR_X)
+#undef GMR_X
   return -1;
 }
 
@@ -106,8 +124,21 @@ template <int NVP>
 void launch_ik(const gmr_model *m, const gmr::IkLaunch &L, hipStream_t st) {
   if (m->dm.sq_ok && !m->force_generic)
     hipLaunchKernelGGL((gmr::ik_kernel<NVP, true>), dim3(L.n_items), dim3(64), m->lds_bytes, st, m->dm, L, m->lay);
+#ifndef GMR_IK_DEV_ONLY36
   else
     hipLaunchKernelGGL((gmr::ik_kernel<NVP, false>), dim3(L.n_items), dim3(64), m->lds_bytes, st, m->dm, L, m->lay);
+#endif
+}
+
+int launch_ik_variant(gmr_model *m, const gmr::IkLaunch &L, hipStream_t st) {
+  switch (m->nvp) {
+#define GMR_X(v) case v: launch_ik<v>(m, L, st); break;
+    GMR_FOR_EACH_NVP(GMR_X)
+#undef GMR_X
+    default: set_err(m, "internal: no kernel variant for nvp=%d", m->nvp); return GMR_EUNSUPPORTED;
+  }
+  HIP_TRY(m, hipGetLastError());
+  return GMR_OK;
 }
 
 int build_device_model(gmr_model *m) {
@@ -473,16 +504,15 @@ int build_device_model(gmr_model *m) {
   m->n_act = n_act;
   if (m->lds_bytes > 160 * 1024) { set_err(m, "model needs %d bytes of LDS per wavefront", m->lds_bytes); return GMR_EUNSUPPORTED; }
   // opt in to > 64 KiB of dynamic LDS where a variant needs it
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<36, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<36, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<40, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<40, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<48, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<48, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#ifdef GMR_IK_DEV_ONLY36
+#define GMR_X(v) hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<v, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#else
+#define GMR_X(v)                                                                                                                        \
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<v, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<v, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
+  GMR_FOR_EACH_NVP(GMR_X)
+#undef GMR_X
   hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::eval_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipGetLastError();
   return GMR_OK;
@@ -605,15 +635,102 @@ int gmr_ik_solve(gmr_model *m, const void *human_pos, const void *human_quat, in
   if (!m->dbg) { HIP_TRY(m, hipMalloc(&m->dbg, 16 * sizeof(unsigned long long))); HIP_TRY(m, hipMemset(m->dbg, 0, 16 * sizeof(unsigned long long))); }
 #endif
   L.dbg = m->dbg;
-  switch (m->nvp) {
-    case 32: launch_ik<32>(m, L, st); break;
-    case 36: launch_ik<36>(m, L, st); break;
-    case 40: launch_ik<40>(m, L, st); break;
-    case 48: launch_ik<48>(m, L, st); break;
-    case 64: launch_ik<64>(m, L, st); break;
-    default: set_err(m, "internal: no kernel variant for nvp=%d", m->nvp); return GMR_EUNSUPPORTED;
-  }
-  HIP_TRY(m, hipGetLastError());
+  return launch_ik_variant(m, L, st);
+}
+
+// ------------------------------------------------------------------ single-sequence sessions (teleop)
+
+gmr_session *gmr_session_create(gmr_model *m, int in_dtype, int n_cols, const int32_t *slot_col, const gmr_ik_params *params) {
+  if (!m) return nullptr;
+  m->err.clear();
+  if (m->h.nslot == 0 || (m->h.ntask[0] == 0 && m->h.ntask[1] == 0)) { set_err(m, "model has no IK config"); return nullptr; }
+  if (!slot_col || !params || n_cols <= 0 || (in_dtype != GMR_DTYPE_F32 && in_dtype != GMR_DTYPE_F64)) { set_err(m, "bad session argument"); return nullptr; }
+  if (params->max_iter < 0 || !(params->damping > 0.0)) { set_err(m, "damping must be > 0 and max_iter >= 0"); return nullptr; }
+  for (int s = 0; s < m->h.nslot; ++s)
+    if (slot_col[s] < 0 || slot_col[s] >= n_cols) { set_err(m, "slot_col[%d]=%d outside [0,%d)", s, slot_col[s], n_cols); return nullptr; }
+  gmr_session *s = new gmr_session();
+  s->m = m;
+  auto fail = [&](const char *what, hipError_t e) -> gmr_session * {
+    set_err(m, "%s failed: %s", what, hipGetErrorString(e));
+    gmr_session_destroy(s);
+    return nullptr;
+  };
+  hipError_t e;
+  if ((e = hipSetDevice(m->device)) != hipSuccess) return fail("hipSetDevice", e);
+  if ((e = hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+  const size_t elt = in_dtype == GMR_DTYPE_F64 ? 8 : 4, nq = (size_t)m->h.nq;
+  s->pos_bytes = (size_t)n_cols * 3 * elt; s->quat_bytes = (size_t)n_cols * 4 * elt;
+  s->quat_off = (s->pos_bytes + 15) & ~size_t(15);
+  s->out_off = (s->quat_off + s->quat_bytes + 15) & ~size_t(15);
+  const size_t host_bytes = s->out_off + (nq + 1) * 8;
+  if ((e = hipHostMalloc(reinterpret_cast<void **>(&s->host), host_bytes, hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc", e);
+  memset(s->host, 0, host_bytes);
+  void *host_dev = nullptr;
+  if ((e = hipHostGetDevicePointer(&host_dev, s->host, 0)) != hipSuccess) return fail("hipHostGetDevicePointer", e);
+  const size_t item_off = (nq * 8 + 15) & ~size_t(15), col_off = item_off + sizeof(gmr_work_item);
+  if ((e = hipMalloc(reinterpret_cast<void **>(&s->dev), col_off + sizeof(int32_t) * (size_t)m->h.nslot)) != hipSuccess) return fail("hipMalloc", e);
+  gmr_work_item w{};
+  w.frame_begin = 0; w.n_burn = 0; w.n_out = 1; w.init_row = 0; w.final_row = 0; w.burn_row = -1;
+  if ((e = hipMemcpy(s->dev + item_off, &w, sizeof(w), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
+  if ((e = hipMemcpy(s->dev + col_off, slot_col, sizeof(int32_t) * (size_t)m->h.nslot, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
+  uint8_t *hd = static_cast<uint8_t *>(host_dev);
+  gmr::IkLaunch &L = s->L;
+  L.hpos = hd; L.hquat = hd + s->quat_off;
+  L.slot_col = reinterpret_cast<const int *>(s->dev + col_off);
+  L.items = reinterpret_cast<const gmr_work_item *>(s->dev + item_off);
+  L.qinit = reinterpret_cast<const double *>(s->dev); L.qfinal = reinterpret_cast<double *>(s->dev);
+  L.qout = reinterpret_cast<double *>(hd + s->out_off); L.iters = reinterpret_cast<int *>(hd + s->out_off + nq * 8);
+  L.in_f64 = in_dtype == GMR_DTYPE_F64; L.n_cols = n_cols; L.n_items = 1; L.prm = *params;
+  L.dbg = nullptr;
+  if (gmr_session_reset(s, nullptr) != GMR_OK) { gmr_session_destroy(s); return nullptr; }
+  return s;
+}
+
+void gmr_session_destroy(gmr_session *s) {
+  if (!s) return;
+  if (s->m && s->m->device >= 0) (void)hipSetDevice(s->m->device);
+  if (s->st) { (void)hipStreamSynchronize(s->st); (void)hipStreamDestroy(s->st); }
+  if (s->host) (void)hipHostFree(s->host);
+  if (s->dev) (void)hipFree(s->dev);
+  delete s;
+}
+
+int gmr_session_reset(gmr_session *s, const double *qpos) {
+  if (!s) return GMR_EINVAL;
+  gmr_model *m = s->m;
+  const double *src = qpos ? qpos : blob_ptr<double>(m->blob, m->h.off_qpos0);
+  HIP_TRY(m, hipSetDevice(m->device));
+  HIP_TRY(m, hipStreamSynchronize(s->st));
+  HIP_TRY(m, hipMemcpy(s->dev, src, sizeof(double) * (size_t)m->h.nq, hipMemcpyHostToDevice));
+  return GMR_OK;
+}
+
+int gmr_session_step(gmr_session *s, const void *human_pos, const void *human_quat, int offset_to_ground, double *qpos_out,
+                     int32_t *solves_out) {
+  if (!s) return GMR_EINVAL;
+  gmr_model *m = s->m;
+  m->err.clear();
+  if (!human_pos || !human_quat || !qpos_out) { set_err(m, "null argument"); return GMR_EINVAL; }
+  memcpy(s->host, human_pos, s->pos_bytes);
+  memcpy(s->host + s->quat_off, human_quat, s->quat_bytes);
+  gmr::IkLaunch L = s->L;
+  L.prm.offset_to_ground = offset_to_ground ? 1 : 0;
+  HIP_TRY(m, hipSetDevice(m->device));
+  int rc = launch_ik_variant(m, L, s->st);
+  if (rc != GMR_OK) return rc;
+  HIP_TRY(m, hipStreamSynchronize(s->st));
+  const size_t nq = (size_t)m->h.nq;
+  memcpy(qpos_out, s->host + s->out_off, nq * 8);
+  if (solves_out) memcpy(solves_out, s->host + s->out_off + nq * 8, sizeof(int32_t));
+  return GMR_OK;
+}
+
+int gmr_session_state(gmr_session *s, double *qpos_out) {
+  if (!s || !qpos_out) return GMR_EINVAL;
+  gmr_model *m = s->m;
+  HIP_TRY(m, hipSetDevice(m->device));
+  HIP_TRY(m, hipStreamSynchronize(s->st));
+  HIP_TRY(m, hipMemcpy(qpos_out, s->dev, sizeof(double) * (size_t)m->h.nq, hipMemcpyDeviceToHost));
   return GMR_OK;
 }
 

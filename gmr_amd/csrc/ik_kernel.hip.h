@@ -45,6 +45,13 @@ typedef unsigned long long u64;
 #define GMR_STAMP(i) do { } while (0)
 #endif
 
+// Throughput attribution (experiments only): -DGMR_DUP_PHASE=p runs phase p of every solve twice (all phases are idempotent),
+// so the launch-time difference to the normal build is what that phase costs at full occupancy (tools/gpu_dup.sh).
+#ifdef GMR_DUP_PHASE
+#define GMR_DUP(p) for (int rep_ = 0, nrep_ = launder(GMR_DUP_PHASE == (p) ? 2 : 1); rep_ < nrep_; ++rep_)
+#else
+#define GMR_DUP(p)
+#endif
 #ifndef GMR_QP_LDS_BCAST
 #define GMR_QP_LDS_BCAST 1
 #endif
@@ -898,12 +905,12 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
       for (;;) {
         // ---- per-task 6x6 blocks ----
         double mu = 0.0;
-        if (is_task) mu = task_block(t_body, xpos, xquat, e, sh, ch, t_wp, t_wr, Bt + kBT * lane);
+        GMR_DUP(3) if (is_task) mu = task_block(t_body, xpos, xquat, e, sh, ch, t_wp, t_wr, Bt + kBT * lane);
         const double diag = prm.damping + prm.lm_damping * wave_sum(mu);
         GMR_STAMP(3);
         // ---- screws S_i (world frame, about the origin) ----
         double Si[6] = {0, 0, 0, 0, 0, 0};
-        if (real_row) {
+        GMR_DUP(4) if (real_row) {
           if (a_kind < 3) {
             Si[a_kind] = 1.0;  // root translation: world aligned
           } else {
@@ -924,7 +931,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         __syncthreads();
         GMR_STAMP(4);
         // ---- composites: Bc[c] = sum of task blocks below the joint ----
-        {  // lane = block element (27 lanes).  Composites are numbered children-first, so one pass in id order builds each
+        GMR_DUP(5) {  // lane = block element (27 lanes).  Composites are numbered children-first, so one pass in id order builds each
            // from <= 4 own task blocks + <= 4 child composites; the plan is wave-uniform (scalar loads), and the <= 8 LDS
            // reads of a composite are issued together.
           const int ec = lane < kBT ? lane : 0;
@@ -953,7 +960,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         __syncthreads();
         GMR_STAMP(5);
         double ci = 0.0, lo = -1e30, hi = 1e30;
-        if (real_row) {
+        GMR_DUP(6) if (real_row) {
           const double *B = Bc + kBT * a_comp;
           double Fi[6];
           sym6_mul(B, Si, Si + 3, Fi, Fi + 3);
@@ -975,7 +982,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         if constexpr (SQ) {
           // structured layout Hs[col * 64 + lane]: every pair lands in the (at most two) rows that carry it
           for (int idx = lane; idx < 1024; idx += 64) Hm[idx] = 0.0;  // same wave: LDS keeps program order, no barrier needed
-          {
+          GMR_DUP(7) {
             int prs[kPairRounds];
             unsigned dst[kPairRounds];
 #pragma unroll
@@ -1012,6 +1019,9 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
             s_hi = prm.limit_gain * (m.arange[2 * gi + 1] - qv);
           }
           double xs;
+#ifdef GMR_DUP_PHASE
+          if (GMR_DUP_PHASE == 8) { int st2 = sq_status; double x2; (void)box_qp_struct(lane, m.sq_nlimb, sq_own, sq_pad, Hm, lds + lay.Lb, s_ci, s_lo, s_hi, st2, x2); asm volatile("" :: "v"(x2)); }
+#endif
           qit = box_qp_struct(lane, m.sq_nlimb, sq_own, sq_pad, Hm, lds + lay.Lb, s_ci, s_lo, s_hi, sq_status, xs);
           __syncthreads();
           if (sq_own) V[sq_g] = xs;  // c is dead: the same array carries dq back to the dof-indexed lanes
@@ -1072,9 +1082,10 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         __syncthreads();
         GMR_STAMP(9);
         ++solves;
-        fk_phase(m, bodyc, nbody, fkrounds, lane, q, xpos, xquat);
+        GMR_DUP(1) fk_phase(m, bodyc, nbody, fkrounds, lane, q, xpos, xquat);
         GMR_STAMP(1);
-        const double next = fast_sqrt(wave_sum(is_task ? task_residual(t_body, t_slot, xpos, xquat, tp, tq, e, sh, ch) : 0.0));
+        double next = 0.0;
+        GMR_DUP(2) next = fast_sqrt(wave_sum(is_task ? task_residual(t_body, t_slot, xpos, xquat, tp, tq, e, sh, ch) : 0.0));
         GMR_STAMP(2);
         if (!first) ++num_iter;
         first = false;

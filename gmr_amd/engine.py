@@ -62,6 +62,9 @@ class Engine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def session(self, slot_col: np.ndarray, n_cols: int, params: Optional[IKParams] = None, dtype=np.float64) -> "Session":
+        return Session(self, slot_col, n_cols, params, dtype)
+
     # ------------------------------------------------------------------
     def ik_solve(self, pos: torch.Tensor, quat: torch.Tensor, slot_col: np.ndarray, items: np.ndarray,
                  params: Optional[IKParams] = None, qpos_init: Optional[torch.Tensor] = None, n_final: int = 0,
@@ -239,3 +242,58 @@ class Engine:
                                          offs.ctypes.data_as(C.c_void_p), len(offs) - 1, _ptr(out), self._stream())
         self._check(rc, "gmr_fk_min_height")
         return out
+
+
+class Session:
+    """One live sequence (``gmr_session_*``): a frame in, a qpos out, warm start kept on the device.
+
+    The latency path behind ``GeneralMotionRetargeting.retarget`` -- what scripts/optitrack_to_robot.py:37-46 and the
+    interactive viewers drive once per captured frame.  Host numpy in, host numpy out; no torch tensors on the path.
+    """
+
+    def __init__(self, engine: Engine, slot_col: np.ndarray, n_cols: int, params: Optional[IKParams] = None, dtype=np.float64):
+        self._e = engine  # keeps the model alive for as long as the session
+        self._lib = engine._lib
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise TypeError("session inputs must be float32 or float64")
+        self.n_cols = int(n_cols)
+        sc = np.ascontiguousarray(slot_col, dtype=np.int32)
+        prm = params or IKParams()
+        self._h = self._lib.gmr_session_create(engine._h, int(self.dtype == np.float64), self.n_cols, sc.ctypes.data, C.byref(prm))
+        if not self._h:
+            msg = self._lib.gmr_last_error(engine._h)
+            raise EngineError(f"gmr_session_create: {msg.decode() if msg else ''}")
+        self._q = np.empty(engine.nq, dtype=np.float64)
+        self._solves = C.c_int32(0)
+
+    def step(self, pos: np.ndarray, quat: np.ndarray, offset_to_ground: bool = False):
+        """pos ``[n_cols, 3]``, quat ``[n_cols, 4]`` wxyz -> (qpos ``[nq]`` float64 (fresh copy), solves spent)."""
+        p = np.ascontiguousarray(pos, dtype=self.dtype)
+        q = np.ascontiguousarray(quat, dtype=self.dtype)
+        if p.shape != (self.n_cols, 3) or q.shape != (self.n_cols, 4):
+            raise ValueError(f"expected pos [{self.n_cols},3] and quat [{self.n_cols},4], got {p.shape} and {q.shape}")
+        rc = self._lib.gmr_session_step(self._h, p.ctypes.data, q.ctypes.data, int(bool(offset_to_ground)), self._q.ctypes.data,
+                                        C.addressof(self._solves))
+        self._e._check(rc, "gmr_session_step")
+        return self._q.copy(), int(self._solves.value)
+
+    def reset(self, qpos: Optional[np.ndarray] = None):
+        q = None if qpos is None else np.ascontiguousarray(qpos, dtype=np.float64).reshape(self._e.nq)
+        self._e._check(self._lib.gmr_session_reset(self._h, None if q is None else q.ctypes.data), "gmr_session_reset")
+
+    def state(self) -> np.ndarray:
+        out = np.empty(self._e.nq, dtype=np.float64)
+        self._e._check(self._lib.gmr_session_state(self._h, out.ctypes.data), "gmr_session_state")
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self._e, "_h", None):
+            self._lib.gmr_session_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 from scipy.spatial.transform import Rotation as R
 
-from ._native import IKParams, WORK_ITEM_DTYPE
+from ._native import IKParams
 from .engine import Engine
 from .ik_config import load_ik_config
 from .mjcf import load_robot
@@ -35,7 +35,7 @@ class _Data:
 
     @property
     def qpos(self) -> np.ndarray:
-        return self._o._state.cpu().numpy()[0]
+        return self._o._qpos.copy()
 
     @property
     def xpos(self) -> np.ndarray:
@@ -115,16 +115,31 @@ class GeneralMotionRetargeting:
     # ------------------------------------------------------------------ state
     def setup_retarget_configuration(self):
         """Reset to ``qpos0`` (what a fresh ``mink.Configuration(model)`` holds, :75)."""
-        self._state = torch.from_numpy(self.model.qpos0.copy()).to(self.device).reshape(1, -1)
+        self._qpos = np.array(self.model.qpos0, dtype=np.float64)  # the current configuration (host copy)
         self.configuration = _Configuration(self)
         self.scaled_human_data = None
-        self._last_pos = None
+        self._last_pos_np = None
         self._col_cache: Dict[Tuple[str, ...], np.ndarray] = {}
-        self._item1 = np.zeros(1, dtype=WORK_ITEM_DTYPE)
-        self._item1["n_out"] = 1
-        self._item1["init_row"] = 0
-        self._item1["final_row"] = 0
-        self._item1["burn_row"] = -1
+        for s in getattr(self, "_sessions", {}).values():
+            s.close()
+        self._sessions: Dict[tuple, object] = {}  # live single-sequence sessions, one per (column layout, solver settings)
+        self._session_key = None
+
+    @property
+    def _state(self) -> torch.Tensor:
+        return torch.from_numpy(self._qpos).to(self.device).reshape(1, -1)
+
+    def _session(self, names: Sequence[str]):
+        """The live session for this frame layout; the warm start follows the object, not the session."""
+        key = (tuple(names), float(self.damping), int(self.max_iter))
+        s = self._sessions.get(key)
+        if s is None:
+            s = self._engine.session(self._columns(names), len(names), self._params(False))
+            self._sessions[key] = s
+        if key != self._session_key:
+            s.reset(self._qpos)
+            self._session_key = key
+        return s
 
     def _params(self, offset_to_ground: bool) -> IKParams:
         return IKParams(damping=self.damping, max_iter=self.max_iter, offset_to_ground=int(bool(offset_to_ground)))
@@ -142,8 +157,8 @@ class GeneralMotionRetargeting:
         human_data = self.to_numpy(human_data)
         names = list(human_data.keys())
         self._last_cols = self._columns(names)
-        self._last_pos = torch.from_numpy(np.stack([np.asarray(human_data[n][0], dtype=np.float64).reshape(3) for n in names])[None]).to(self.device)
-        self._last_quat = torch.from_numpy(np.stack([np.asarray(human_data[n][1], dtype=np.float64).reshape(4) for n in names])[None]).to(self.device)
+        self._last_pos_np = np.stack([np.asarray(human_data[n][0], dtype=np.float64).reshape(3) for n in names])
+        self._last_quat_np = np.stack([np.asarray(human_data[n][1], dtype=np.float64).reshape(4) for n in names])
         self._last_offset_to_ground = offset_to_ground
         human_data = self.scale_human_data(human_data, self.human_root_name, self.human_scale_table)
         human_data = self.offset_human_data(human_data, self.pos_offsets1, self.rot_offsets1)
@@ -156,26 +171,25 @@ class GeneralMotionRetargeting:
         human_data = self.to_numpy(human_data)  # mutates the caller's dict like the reference (:203-206)
         names = list(human_data.keys())
         cols = self._columns(names)  # KeyError exactly where the reference raises
-        pos = np.stack([np.asarray(human_data[n][0], dtype=np.float64).reshape(3) for n in names])[None]
-        quat = np.stack([np.asarray(human_data[n][1], dtype=np.float64).reshape(4) for n in names])[None]
+        pos = np.stack([np.asarray(human_data[n][0], dtype=np.float64).reshape(3) for n in names])
+        quat = np.stack([np.asarray(human_data[n][1], dtype=np.float64).reshape(4) for n in names])
         self._last_human_data = human_data
         self._last_offset_to_ground = offset_to_ground
         self.scaled_human_data = _LazyScaled(self)
-        self._last_pos, self._last_quat, self._last_cols = torch.from_numpy(pos).to(self.device), torch.from_numpy(quat).to(self.device), cols
-        out, iters, fin = self._engine.ik_solve(
-            self._last_pos, self._last_quat, cols, self._item1,
-            params=self._params(offset_to_ground), qpos_init=self._state, n_final=1)
-        self._state = fin
-        q = out.cpu().numpy()[0]
-        self.last_num_solves = int(iters.cpu().numpy()[0]) & 0x3FFFFFFF
+        self._last_pos_np, self._last_quat_np, self._last_cols = pos, quat, cols
+        q, solves = self._session(names).step(pos, quat, offset_to_ground)
+        self.last_num_solves = solves & 0x3FFFFFFF
         if not np.all(np.isfinite(q)):
             raise FloatingPointError("retarget produced non-finite qpos")
+        self._qpos = q
         return q.copy()
 
     def _errors(self) -> np.ndarray:
-        if getattr(self, "_last_pos", None) is None:
+        if getattr(self, "_last_pos_np", None) is None:
             raise RuntimeError("no targets set: call retarget() or update_targets() first")  # mink raises TargetNotSet
-        e, _, _ = self._engine.evaluate(self._state, self._last_pos, self._last_quat, self._last_cols,
+        pos = torch.from_numpy(self._last_pos_np[None]).to(self.device)
+        quat = torch.from_numpy(self._last_quat_np[None]).to(self.device)
+        e, _, _ = self._engine.evaluate(self._state, pos, quat, self._last_cols,
                                         offset_to_ground=self._last_offset_to_ground)
         return e.cpu().numpy()[0]
 

@@ -21,6 +21,9 @@
  *                      (motion_retarget.py:117-200) and, inside it, mink.solve_ik +
  *                      Configuration.integrate_inplace (call sites motion_retarget.py:147-150,156-159,
  *                      166-169,176-179)
+ *   gmr_session_*      the live loop of scripts/optitrack_to_robot.py:37-46 / smplx_to_robot.py:103-126 / bvh_to_robot.py:
+ *                      one frame in, one qpos out, state carried inside (`retargeter.retarget(frame)` called once per
+ *                      captured frame): a latency path next to the throughput path of gmr_ik_solve
  *   gmr_evaluate       error1() / error2() (motion_retarget.py:188-200) and configuration.data.xpos / xquat
  *                      (mink.Configuration.update = mj_kinematics) at given qpos, without solving
  *   gmr_fk             KinematicsModel.forward_kinematics (kinematics_model.py:213-246)
@@ -100,6 +103,23 @@ int gmr_ik_solve(gmr_model *m, const void *human_pos, const void *human_quat, in
                  const int32_t *slot_col, int64_t n_frames, const gmr_work_item *items, int n_items,
                  const gmr_ik_params *params, const double *qpos_init, double *qpos_final, double *qpos_out,
                  int32_t *iters_out, gmr_ik_stats *stats, void *stream);
+
+/* Single-sequence sessions ("teleop"): one frame per call, warm start carried in the session -- the semantics of calling
+ * GeneralMotionRetargeting.retarget once per captured frame (motion_retarget.py:139-185).  Inputs and outputs are HOST
+ * pointers: the session owns pinned, device-visible staging that the kernel reads and writes directly (no copy engines on
+ * the path), one launch per frame on the session's own stream; gmr_session_step returns when qpos_out is filled.
+ *   slot_col/in_dtype/n_cols/params as in gmr_ik_solve (params->offset_to_ground is overridden per step)
+ *   human_pos host [n_cols][3], human_quat host [n_cols][4] wxyz, qpos_out host [nq] f64, solves_out host int32 or NULL
+ *   gmr_session_reset: qpos host [nq] or NULL (= the model's qpos0, a fresh mink.Configuration)
+ *   gmr_session_state: copies the current configuration to host [nq]
+ * A session borrows its model: destroy sessions before the model.  Errors are reported on the model (gmr_last_error).     */
+typedef struct gmr_session gmr_session;
+gmr_session *gmr_session_create(gmr_model *m, int in_dtype, int n_cols, const int32_t *slot_col, const gmr_ik_params *params);
+void gmr_session_destroy(gmr_session *s);
+int gmr_session_reset(gmr_session *s, const double *qpos);
+int gmr_session_step(gmr_session *s, const void *human_pos, const void *human_quat, int offset_to_ground, double *qpos_out,
+                     int32_t *solves_out);
+int gmr_session_state(gmr_session *s, double *qpos_out);
 
 /* Evaluate, per frame, the stage errors |concat_t Log(T_body^-1 T_target)| of both tables and/or the MuJoCo-convention FK.
  *   qpos device [n][nq] f64;  human_pos/human_quat/in_dtype/n_cols/slot_col as in gmr_ik_solve (needed only with err_out)

@@ -388,3 +388,54 @@ def test_smplx_keypoint_adapter_matches_scipy_restatement(src_fps):
     g = GMR("smplx", "unitree_g1")
     q = g.retarget_batch(pos, quat, names)  # 55 columns, the config picks its 14
     assert q.shape == (pos.shape[0], 36) and bool(torch.isfinite(q).all())
+
+
+def test_session_single_sequence_mode_matches_oracle():
+    """gmr_session_*: the live per-frame path (scripts/optitrack_to_robot.py:37-46): state carried in the session, f32 and
+    f64 inputs, reset / state accessors, argument checks, a layout switch mid-stream keeps the warm start."""
+    import time
+    from gmr_amd.engine import Engine, EngineError
+    from gmr_amd._native import IKParams
+    cm = compiled("smplx", "unitree_g1")
+    eng = Engine(cm)
+    T = 40
+    pos, quat, names, offs, _ = synth.synth_clips(cm, 1, T, seed=11, hard=True, dtype=np.float32)
+    sc = cm.slot_columns(names)
+    orc = Oracle(cm.blob)
+    q_ref, it_ref, _ = orc.ik_solve(pos, quat, sc, make_items(offs))
+    s32 = eng.session(sc, pos.shape[1], IKParams(), dtype=np.float32)
+    lat = []
+    for f in range(T):
+        t0 = time.perf_counter()
+        q, n = s32.step(pos[f], quat[f])
+        lat.append(time.perf_counter() - t0)
+        assert np.abs(q - q_ref[f]).max() < 1e-6 and (n & 0x3FFFFFFF) == it_ref[f]
+    print(f"session step latency: median {1e6 * np.median(lat):.0f} us, max {1e6 * np.max(lat):.0f} us")
+    assert np.array_equal(s32.state(), q)
+    # reset to qpos0 reproduces frame 0; reset to a given configuration continues from it
+    s32.reset()
+    assert np.abs(s32.step(pos[0], quat[0])[0] - q_ref[0]).max() < 1e-6
+    s32.reset(q_ref[9])
+    assert np.abs(s32.step(pos[10], quat[10])[0] - q_ref[10]).max() < 1e-6
+    # float64 inputs, offset_to_ground per step
+    s64 = eng.session(sc, pos.shape[1], IKParams(), dtype=np.float64)
+    p64, q64 = pos.astype(np.float64), quat.astype(np.float64)
+    qg_ref, _, _ = orc.ik_solve(p64[:3], q64[:3], sc, make_items([0, 3]), params=OParams(offset_to_ground=1))
+    for f in range(3):
+        assert np.abs(s64.step(p64[f], q64[f], offset_to_ground=True)[0] - qg_ref[f]).max() < 1e-6
+    with pytest.raises(ValueError):
+        s64.step(p64[0][:-1], q64[0])
+    with pytest.raises(EngineError):
+        eng.session(np.full_like(sc, 99), pos.shape[1])
+    with pytest.raises(EngineError):
+        eng.session(sc, pos.shape[1], IKParams(damping=0.0))
+    s32.close(); s64.close()
+    # the class API rides on sessions: switching the dict layout mid-stream keeps the warm start
+    from gmr_amd import GeneralMotionRetargeting as GMR
+    g = GMR("smplx", "unitree_g1", actual_human_height=1.8)
+    sub = [n for n in names]
+    for f in range(4):
+        g.retarget(_frames(pos, quat, names, f))
+    rev = list(reversed(sub))
+    d = {n: (pos[4][names.index(n)], quat[4][names.index(n)]) for n in rev}
+    assert np.abs(g.retarget(d) - q_ref[4]).max() < 1e-6 and len(g._sessions) == 2

@@ -1,26 +1,33 @@
 #!/bin/bash
-# PMC passes over the IK kernel (600-frame bench) + occupancy experiment.  Outputs under gpurun_out/.
+# PMC passes over the IK kernel (2048 x 300 bench launch).  Outputs under gpurun_out/pmcq.log.
+# Each pass is its own rocprofv3 run (--pmc with --kernel-trace only); a pass naming an unknown counter just fails.
 set -o pipefail
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+: > gpurun_out/pmcq.log
 i=0
-for C in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_IFETCH" "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+while read -r C; do
+  [ -z "$C" ] && continue
   i=$((i+1))
-  (cd /tmp && timeout -k 10 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmcq_$i -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu --frames 300 > /dev/null 2>$R/gpurun_out/pmcq_$i.err)
-  f=$(find gpurun_out/pmcq_$i -name "*counter_collection.csv" | head -1)
-  echo "== pass $i $f" | tee -a gpurun_out/pmcq.log
-  python3 - "$f" <<'PY' | tee -a gpurun_out/pmcq.log
+  (cd /tmp && timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $R/gpurun_out/pmcq_$i -- python3 $R/bench.py --steps 1 --warmup 1 --hot-only --frames 300 > /dev/null 2>$R/gpurun_out/pmcq_$i.err)
+  rc=$?
+  f=$(find gpurun_out/pmcq_$i -name "*counter_collection.csv" 2>/dev/null | head -1)
+  echo "== pass $i rc=$rc [$C]" | tee -a gpurun_out/pmcq.log
+  [ -n "$f" ] && python3 - "$f" <<'PY' | tee -a gpurun_out/pmcq.log
 import csv, sys, collections
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
     if 'ik_kernel' in r['Kernel_Name']:
         acc[r['Counter_Name']].append(float(r['Counter_Value']))
 for k, v in acc.items():
-    print(f"{k:24s} {v[-1]:.4g}  (dispatches {len(v)})")
+    print(f"{k:28s} {v[-1]:.5g}  (dispatches {len(v)})")
 PY
-done
-for S in 256 512 1024 2048 4096; do
-  echo "== clips $S" | tee -a gpurun_out/pmcq.log
-  timeout -k 10 300 python bench.py --steps 2 --warmup 1 --frames 300 --no-cpu --clips $S 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['kernel_ms'])" | tee -a gpurun_out/pmcq.log
-done
+done <<'LIST'
+SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS
+SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU
+SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT
+SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32
+SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INST_LEVEL_LDS
+SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_INSTS_BRANCH SQ_INSTS_SENDMSG SQ_INSTS_EXP_GDS SQ_INSTS_FLAT
+LIST
