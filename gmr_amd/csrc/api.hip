@@ -403,6 +403,103 @@ int build_device_model(gmr_model *m) {
       comp_own[k * 32 + o] = own; comp_kids[k * 32 + o] = kids;
     }
   }
+  const int ns = h.nslot;
+  // ---- LDS layout of the IK kernel (doubles).  Lifetimes inside one solve:
+  //   poses (FK .. screws) | Bt (task blocks .. composites) | Bc (composites .. F)   -> Bc overwrites the dead poses
+  //   S, F (screws / F .. H assembly)                                                 -> the factorisation's broadcast rows Lb overwrite S
+  //   H (H assembly .. QP) overwrites [Bt | poses/Bc];  V (structured QP only): c in / dq out, per dof
+  const int ntmax = std::max(h.ntask[0], h.ntask[1]), ncmax = std::max(ncomp[0], ncomp[1]);
+  const bool sq = sq_ok && !m->force_generic;
+  gmr::LdsLayout &L = m->lay;  // (named L here; the composite plan below needs the byte offsets)
+  auto even = [](int x) { return (x + 1) & ~1; };
+  int o = 0;
+  L.zero = o; o += 2;  // [0] stays 0.0 (absent block of the composite plan), [1] absorbs idle lanes' writes
+  L.q = o; o += even(nq);
+  L.tp = o; o += even(3 * ns);
+  L.tq = o; o += 4 * ns;
+  L.V = o; o += sq ? even(n_act) : 0;
+  L.bodyc = GMR_IK_STAGE_TREE ? o : -1; o += GMR_IK_STAGE_TREE ? even(gmr::kBodyC * nb) : 0;
+  L.S = o; L.Lb = o; o += std::max(6 * nvp, sq ? 128 : 2 * (nvp + 2));
+  L.F = o; o += 6 * nvp;
+  L.B = o; L.H = o;
+  const int bt = even(gmr::kBT * ntmax), px = std::max(even(7 * nb), even(gmr::kBT * ncmax));
+  L.xpos = o + bt; L.xquat = L.xpos + even(3 * nb); L.Bc = o + bt;
+  o += std::max(bt + px, (sq ? 1024 : nvp * nvp) + 2);  // + a dummy slot for the unused lanes of the pair rounds
+  L.total_doubles = o;
+  m->lds_bytes = o * (int)sizeof(double);
+  m->nvp = nvp;
+  m->n_act = n_act;
+  // ---- composite plan: passes of <= 2 entries, an entry = one composite summed from <= 4 blocks, children before parents ----
+  if (m->lds_bytes > 65535) { set_err(m, "model needs %d bytes of LDS per wavefront (plan offsets are 16 bit)", m->lds_bytes); return GMR_EUNSUPPORTED; }
+  std::vector<uint32_t> comp_plan((size_t)2 * gmr::kMaxCompPass * 64 * 4, 0u);
+  int ncpass[2] = {0, 0};
+  for (int k = 0; k < 2; ++k) {
+    struct Entry { int dst; std::vector<int> src; std::vector<int> deps; int done_pass = -1; int height = 0; };
+    // src / dst are block ids: task t -> t, composite c -> 64 + c;  deps: entries that must have run in an earlier pass
+    std::vector<Entry> ent;
+    std::vector<int> last_entry_of_comp(ncomp[k], -1);
+    for (int c = 0; c < ncomp[k]; ++c) {
+      std::vector<int> srcs, deps;
+      for (unsigned own = comp_own[k * 32 + c]; own; own &= own - 1) srcs.push_back(__builtin_ctz(own));
+      for (unsigned kids = comp_kids[k * 32 + c]; kids; kids &= kids - 1) {
+        const int d = __builtin_ctz(kids);
+        srcs.push_back(64 + d);
+      }
+      // children first in the source list of the *last* entry would lengthen the chain; put finished-early blocks (tasks) last
+      std::stable_sort(srcs.begin(), srcs.end(), [](int a, int b) { return (a >= 64) > (b >= 64); });
+      size_t i = 0;
+      bool first = true;
+      while (i < srcs.size() || first) {
+        Entry e;
+        e.dst = 64 + c;
+        if (!first) { e.src.push_back(64 + c); e.deps.push_back(last_entry_of_comp[c]); }
+        while (i < srcs.size() && e.src.size() < 4) {
+          const int sidx = srcs[i++];
+          e.src.push_back(sidx);
+          if (sidx >= 64) e.deps.push_back(last_entry_of_comp[sidx - 64]);
+        }
+        last_entry_of_comp[c] = (int)ent.size();
+        ent.push_back(std::move(e));
+        first = false;
+      }
+    }
+    const int ne = (int)ent.size();
+    // height = longest chain of dependants above an entry (critical-path priority)
+    for (int i = ne - 1; i >= 0; --i)
+      for (int d : ent[i].deps) ent[d].height = std::max(ent[d].height, ent[i].height + 1);
+    int done = 0, pass = 0;
+    const int boff = m->lay.B * 8, coff = m->lay.Bc * 8, zoff = m->lay.zero * 8;
+    auto block_off = [&](int id) { return id >= 64 ? coff + gmr::kBT * 8 * (id - 64) : boff + gmr::kBT * 8 * id; };
+    while (done < ne) {
+      if (pass >= gmr::kMaxCompPass) { set_err(m, "composite plan of table %d needs more than %d passes", k + 1, gmr::kMaxCompPass); return GMR_EUNSUPPORTED; }
+      int pick[2] = {-1, -1};
+      for (int slot = 0; slot < 2; ++slot) {
+        int best = -1;
+        for (int i = 0; i < ne; ++i) {
+          if (ent[i].done_pass >= 0 || i == pick[0]) continue;
+          bool ready = true;
+          for (int d : ent[i].deps) ready = ready && ent[d].done_pass >= 0 && ent[d].done_pass < pass;
+          if (ready && (best < 0 || ent[i].height > ent[best].height)) best = i;
+        }
+        pick[slot] = best;
+      }
+      if (pick[0] < 0) { set_err(m, "internal: composite plan stalled"); return GMR_EINVAL; }
+      uint32_t *row = comp_plan.data() + ((size_t)(k * gmr::kMaxCompPass + pass) * 64) * 4;
+      for (int lane = 0; lane < 64; ++lane) {
+        const int half = lane >> 5, el = lane & 31, ei = pick[half];
+        uint32_t so[4] = {(uint32_t)zoff, (uint32_t)zoff, (uint32_t)zoff, (uint32_t)zoff}, dst = (uint32_t)zoff + 8;
+        if (ei >= 0 && el < gmr::kBT) {
+          for (size_t j = 0; j < ent[ei].src.size(); ++j) so[j] = (uint32_t)(block_off(ent[ei].src[j]) + 8 * el);
+          dst = (uint32_t)(block_off(ent[ei].dst) + 8 * el);
+        }
+        row[4 * lane + 0] = so[0] | (so[1] << 16); row[4 * lane + 1] = so[2] | (so[3] << 16); row[4 * lane + 2] = dst; row[4 * lane + 3] = 0;
+      }
+      for (int slot = 0; slot < 2; ++slot)
+        if (pick[slot] >= 0) { ent[pick[slot]].done_pass = pass; ++done; }
+      ++pass;
+    }
+    ncpass[k] = pass;
+  }
   // ---- FK (KinematicsModel convention) tables and branch-slot plan ----
   std::vector<int> dofidx(nb, -1), src_slot(nb, -1), save_slot(nb, -1), last_child(nb, -1), nchild_other(nb, 0);
   std::vector<float> lpos(3 * nb), lrot(4 * nb), jaxis(3 * nb);
@@ -432,7 +529,6 @@ int build_device_model(gmr_model *m) {
   // ---- pack + upload ----
   std::vector<int> v_parent(parent, parent + nb), v_jtype(jtype, jtype + nb), v_qadr(qadr, qadr + nb);
   std::vector<double> v_bpos(bpos, bpos + 3 * nb), v_bquat(bquat, bquat + 4 * nb), v_axis(axis, axis + 3 * nb), v_qpos0(qpos0, qpos0 + nq);
-  const int ns = h.nslot;
   std::vector<double> v_sscale(blob_ptr<double>(B, h.off_slot_scale), blob_ptr<double>(B, h.off_slot_scale) + ns);
   std::vector<double> v_spoff(blob_ptr<double>(B, h.off_slot_pos_off), blob_ptr<double>(B, h.off_slot_pos_off) + 3 * ns);
   std::vector<double> v_sroff(blob_ptr<double>(B, h.off_slot_rot_off), blob_ptr<double>(B, h.off_slot_rot_off) + 4 * ns);
@@ -446,7 +542,7 @@ int build_device_model(gmr_model *m) {
   const size_t o_tbody = P.add(tbody), o_tslot = P.add(tslot), o_twp = P.add(twp), o_twr = P.add(twr);
   const size_t o_abody = P.add(abody), o_akind = P.add(akind), o_aqadr = P.add(aqadr), o_alim = P.add(alim);
   const size_t o_aanc = P.add(aanc), o_arange = P.add(arange), o_acomp = P.add(acomp), o_compmask = P.add(compmask);
-  const size_t o_hpair = P.add(hpair), o_fkanc = P.add(fkanc), o_cown = P.add(comp_own), o_ckids = P.add(comp_kids);
+  const size_t o_hpair = P.add(hpair), o_fkanc = P.add(fkanc), o_cplan = P.add(comp_plan);
   const size_t o_sqg = P.add(sq_gdof), o_sqo = P.add(sq_owner), o_sql = P.add(sq_lane_of_dof), o_sqd = P.add(sq_diag), o_sqdst = P.add(sq_dst);
   const size_t o_dm = P.add(std::vector<gmr::DevModel>(1));
   const size_t o_dofidx = P.add(dofidx), o_src = P.add(src_slot), o_save = P.add(save_slot);
@@ -465,7 +561,7 @@ int build_device_model(gmr_model *m) {
   dm.tbody = DP(int, o_tbody); dm.tslot = DP(int, o_tslot); dm.twp = DP(double, o_twp); dm.twr = DP(double, o_twr);
   dm.abody = DP(int, o_abody); dm.akind = DP(int, o_akind); dm.aqadr = DP(int, o_aqadr); dm.alimited = DP(int, o_alim);
   dm.aanc = DP(u64, o_aanc); dm.arange = DP(double, o_arange); dm.acomp = DP(int, o_acomp); dm.compmask = DP(unsigned, o_compmask);
-  dm.hpair = DP(unsigned short, o_hpair); dm.comp_own = DP(unsigned, o_cown); dm.comp_kids = DP(unsigned, o_ckids); dm.npair = (int)hpair.size(); dm.fkanc = DP(u64, o_fkanc); dm.fkrounds = fkrounds;
+  dm.hpair = DP(unsigned short, o_hpair); dm.comp_plan = DP(uint4, o_cplan); dm.ncpass[0] = ncpass[0]; dm.ncpass[1] = ncpass[1]; dm.npair = (int)hpair.size(); dm.fkanc = DP(u64, o_fkanc); dm.fkrounds = fkrounds;
   dm.sq_gdof = DP(signed char, o_sqg); dm.sq_owner = DP(signed char, o_sqo); dm.sq_lane_of_dof = DP(int, o_sql); dm.sq_diag = DP(int, o_sqd);
   dm.sq_dst = DP(unsigned, o_sqdst); dm.sq_ok = sq_ok; dm.sq_nlimb = sq_nlimb;
   m->dm_dev = DP(gmr::DevModel, o_dm);
@@ -478,30 +574,6 @@ int build_device_model(gmr_model *m) {
   HIP_TRY(m, hipMemcpy(m->dev, P.buf.data(), P.buf.size(), hipMemcpyHostToDevice));
   m->fk_lds_bytes = std::max(1, nslots) * 7 * gmr::kFkThreads * (int)sizeof(float);
 
-  // ---- LDS layout of the IK kernel (doubles).  Lifetimes inside one solve:
-  //   poses (FK .. screws) | Bt (task blocks .. composites) | Bc (composites .. F)   -> Bc overwrites the dead poses
-  //   S, F (screws / F .. H assembly)                                                 -> the factorisation's broadcast rows Lb overwrite S
-  //   H (H assembly .. QP) overwrites [Bt | poses/Bc];  V (structured QP only): c in / dq out, per dof
-  const int ntmax = std::max(h.ntask[0], h.ntask[1]), ncmax = std::max(ncomp[0], ncomp[1]);
-  const bool sq = sq_ok && !m->force_generic;
-  gmr::LdsLayout &L = m->lay;
-  auto even = [](int x) { return (x + 1) & ~1; };
-  int o = 0;
-  L.q = o; o += even(nq);
-  L.tp = o; o += even(3 * ns);
-  L.tq = o; o += 4 * ns;
-  L.V = o; o += sq ? even(n_act) : 0;
-  L.bodyc = GMR_IK_STAGE_TREE ? o : -1; o += GMR_IK_STAGE_TREE ? even(gmr::kBodyC * nb) : 0;
-  L.S = o; L.Lb = o; o += std::max(6 * nvp, sq ? 128 : 2 * (nvp + 2));
-  L.F = o; o += 6 * nvp;
-  L.B = o; L.H = o;
-  const int bt = even(gmr::kBT * ntmax), px = std::max(even(7 * nb), even(gmr::kBT * ncmax));
-  L.xpos = o + bt; L.xquat = L.xpos + even(3 * nb); L.Bc = o + bt;
-  o += std::max(bt + px, (sq ? 1024 : nvp * nvp) + 2);  // + a dummy slot for the unused lanes of the pair rounds
-  L.total_doubles = o;
-  m->lds_bytes = o * (int)sizeof(double);
-  m->nvp = nvp;
-  m->n_act = n_act;
   if (m->lds_bytes > 160 * 1024) { set_err(m, "model needs %d bytes of LDS per wavefront", m->lds_bytes); return GMR_EUNSUPPORTED; }
   // opt in to > 64 KiB of dynamic LDS where a variant needs it
 #ifdef GMR_IK_DEV_ONLY36

@@ -66,6 +66,7 @@ typedef unsigned long long u64;
 #endif
 
 constexpr int kBT = 27;  // doubles per task block: LL(6) LA(9) AA(6) g(6)
+constexpr int kMaxCompPass = 32;  // passes of the composite plan (two composites per pass, children before parents)
 constexpr double kLieEps = 1e-10;  // mink.lie.utils.get_epsilon(float64)
 
 // Device view of a compiled model: pointers into one device allocation (see api.hip).
@@ -90,7 +91,8 @@ struct DevModel {
   const unsigned *compmask;                     // [2][GMR_MAX_TASKS*2] tasks summed into each composite
   const unsigned short *hpair;                  // [npair] (i << 8) | j for every dof j strictly above dof i
   const u64 *fkanc;                             // [nbody] byte r = ancestor folded in FK round r (0xff: none)
-  const unsigned *comp_own, *comp_kids;         // [2][32] per composite: its own tasks / its child composites (lower ids)
+  const uint4 *comp_plan;                       // [2][kMaxCompPass][64] per pass and lane: LDS byte offsets {s0|s1<<16, s2|s3<<16, dst, -}
+  int ncpass[2];                                // composite passes per table
   // structured QP (box_qp_struct): 4 groups of 16 lanes, each = one bin of limb dofs + a copy of the core dofs
   const signed char *sq_gdof, *sq_owner;        // [64] dof of a structured lane (-1 padding); 1 if the lane owns that dof
   const int *sq_lane_of_dof, *sq_diag;          // [64] per dof: its owner lane; LDS index of its diagonal entry
@@ -99,7 +101,7 @@ struct DevModel {
 };
 
 struct LdsLayout {
-  int q, tp, tq, S, F, Lb, V, bodyc, xpos, xquat, B, Bc, H, total_doubles;  // H aliases [xpos, xquat, B, Bc] (dead during the QP)
+  int zero, q, tp, tq, S, F, Lb, V, bodyc, xpos, xquat, B, Bc, H, total_doubles;  // H aliases [xpos, xquat, B, Bc] (dead during the QP)
 };
 
 struct IkLaunch {
@@ -796,6 +798,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
   const unsigned short *pairs = m.hpair;  // read through L2 each solve (laundered index)
   double *bodyc = lay.bodyc >= 0 ? lds + lay.bodyc : nullptr;
   if (bodyc) stage_tree(m, lane, bodyc);
+  if (lane == 0) lds[lay.zero] = 0.0;  // the composite plan's "absent block" (never aliased); lds[lay.zero + 1] absorbs idle lanes' writes
   const gmr_work_item w = L.items[blockIdx.x];
   const gmr_ik_params prm = L.prm;
 #ifdef GMR_IK_STAMPS
@@ -931,30 +934,20 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         __syncthreads();
         GMR_STAMP(4);
         // ---- composites: Bc[c] = sum of task blocks below the joint ----
-        GMR_DUP(5) {  // lane = block element (27 lanes).  Composites are numbered children-first, so one pass in id order builds each
-           // from <= 4 own task blocks + <= 4 child composites; the plan is wave-uniform (scalar loads), and the <= 8 LDS
-           // reads of a composite are issued together.
-          const int ec = lane < kBT ? lane : 0;
-          const unsigned *cown = m.comp_own + 32 * tab, *ckids = m.comp_kids + 32 * tab;
-          for (int c = 0; c < ncomp; ++c) {
-            unsigned own = cown[c], kids = ckids[c];
-            double v[8];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-              const bool on = own != 0;
-              const int t = on ? __builtin_ctz(own) : 0;
-              own &= own - 1;
-              v[k] = on ? Bt[kBT * t + ec] : 0.0;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-              const bool on = kids != 0;
-              const int d = on ? __builtin_ctz(kids) : 0;
-              kids &= kids - 1;
-              v[4 + k] = on ? Bc[kBT * d + ec] : 0.0;
-            }
-            const double s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-            if (lane < kBT) Bc[kBT * c + lane] = s;
+        GMR_DUP(5) {  // Composites are built children-first by a host-made plan: each pass, lanes 0..26 and 32..58 each sum up to four
+                      // blocks (task blocks or finished composites) into one composite, element per lane.  A lane's plan entry is
+                      // four source byte offsets (absent ones point at a zero) and a destination; no masks, no selects.  Same
+                      // wave, so LDS program order makes a pass see the previous one's writes without a barrier.
+          const uint4 *plan = m.comp_plan + tab * (kMaxCompPass * 64) + lane;
+          const int np = m.ncpass[tab];
+          char *lb = reinterpret_cast<char *>(lds);
+          uint4 nxt = plan[0];
+          for (int p = 0; p < np; ++p) {
+            const uint4 cur = nxt;
+            if (p + 1 < np) nxt = plan[launder((p + 1) * 64)];
+            const double v0 = *reinterpret_cast<const double *>(lb + (cur.x & 0xffffu)), v1 = *reinterpret_cast<const double *>(lb + (cur.x >> 16));
+            const double v2 = *reinterpret_cast<const double *>(lb + (cur.y & 0xffffu)), v3 = *reinterpret_cast<const double *>(lb + (cur.y >> 16));
+            *reinterpret_cast<double *>(lb + cur.z) = (v0 + v1) + (v2 + v3);
           }
         }
         __syncthreads();
