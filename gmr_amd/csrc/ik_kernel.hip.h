@@ -58,6 +58,9 @@ typedef unsigned long long u64;
 #ifndef GMR_QP_GROUP
 #define GMR_QP_GROUP 6
 #endif
+#ifndef GMR_SQ_ELIM_DPP
+#define GMR_SQ_ELIM_DPP 1  // structured QP: pivot rows by DPP row_newbcast (1) or through two LDS rows (0)
+#endif
 #ifndef GMR_IK_STAGE_TREE
 #define GMR_IK_STAGE_TREE 1  // joint tree staged in LDS per wavefront; 0 = re-read from L2 (saves 3.3 KB LDS for G1)
 #endif
@@ -633,11 +636,25 @@ __device__ __forceinline__ int box_qp(int lane, int n_act, const double *Hm, dou
 // ds_write_b64 pair (column entry, rhs) and group-addressed ds_read_b128 broadcasts; LDL' without square roots; the pivot
 // lane keeps its raw row, which is what the back-substitution consumes.  16 registers per row instead of NVP.
 template <int K>
-__device__ __forceinline__ double group_bcast(double v) {  // value of lane (lane & 48) + K
-  // ds_swizzle bit mode works inside 32-lane halves: src = (lane & 0x10) | K
-  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x10 | (K << 5));
-  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x10 | (K << 5));
-  return __hiloint2double(hi, lo);
+__device__ __forceinline__ double group_bcast(double v) {  // value of lane (lane & 48) + K: one v_mov_b64_dpp row_newbcast, no LDS
+  return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xf, 0xf, false);
+}
+// v summed over the four 16-lane groups (same local lane), result in every group: gfx950 v_permlane{16,32}_swap, no LDS.
+// permlane16_swap(x, x) leaves {rows 0,0,2,2} in the first operand and {rows 1,1,3,3} in the second; permlane32_swap the halves.
+__device__ __forceinline__ double group_sum4(double v) {
+  {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+  }
+  {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    v = __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+  }
+  return v;
 }
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F &&f) {  // f(std::integral_constant<int, I>) for I in [I, N)
@@ -697,6 +714,23 @@ __device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool 
     }
     // ---- elimination of local pivot k in every group; the limb pivots first, then (after the cross-group sum) the core ----
     double myinvd = 1.0;
+#if GMR_SQ_ELIM_DPP
+    // pivot k of every group at once: d_k and b_k come from the pivot lane, column k (= row k by symmetry) entry by entry from
+    // the lanes below it, all by row_newbcast -- no LDS, no barrier
+    auto step = [&](auto K) {
+      constexpr int k = K;
+      const double invd = fast_rcp(group_bcast<k>(R[k]));
+      const double u = a > k ? R[k] * invd : 0.0;
+      myinvd = a == k ? invd : myinvd;
+      const double bk = group_bcast<k>(bb);
+      static_for<k + 1, 16>([&](auto J) {
+        constexpr int jj = J;
+        R[jj] -= u * group_bcast<jj>(R[k]);
+      });
+      bb -= u * bk;
+    };
+    static_for<0, 10>([&](auto K) { if (K < nl) step(K); });  // wave-uniform
+#else
     auto step = [&](const int k) {
       Cc[lane] = R[k];  // = H^(k)[a][k] = H^(k)[k][a]
       Cr[lane] = bb;
@@ -717,23 +751,26 @@ __device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool 
 #pragma unroll
     for (int k = 0; k < 10; k++)
       if (k < nl) step(k);  // wave-uniform
+#endif
     // every copy of the core block / rhs <- sum over the four groups
 #pragma unroll
     for (int b = 6; b < 16; b++) {
       if (b >= nl) {
-        double t = R[b] + __shfl_xor(R[b], 16);
-        t += __shfl_xor(t, 32);
+        const double t = group_sum4(R[b]);
         R[b] = core_row ? t : R[b];
       }
     }
     {
-      double t = bb + __shfl_xor(bb, 16);
-      t += __shfl_xor(t, 32);
+      const double t = group_sum4(bb);
       bb = core_row ? t : bb;
     }
+#if GMR_SQ_ELIM_DPP
+    static_for<6, 16>([&](auto K) { if (K >= nl) step(K); });
+#else
 #pragma unroll
     for (int k = 6; k < 16; k++)
       if (k >= nl) step(k);
+#endif
     // ---- back-substitution, k = 15 .. 0: x_k = (y_k - sum_{b>k} R_k[b] x_b) / d_k ----
     static_for_down<0, 16>([&](auto K) {
       constexpr int k = K;
@@ -773,8 +810,7 @@ __device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool 
         constexpr int b = B;
         hx += Hs[b * 64 + lane] * group_bcast<b>(xe2);
       });
-      double t = hx + __shfl_xor(hx, 16);
-      t += __shfl_xor(t, 32);
+      const double t = group_sum4(hx);
       hx = core_row ? t : hx;
     }
     const double g = ci + hx;
