@@ -41,6 +41,8 @@ typedef unsigned long long u64;
 
 #ifdef GMR_IK_STAMPS  // diagnostic build only: per-phase cycle shares (tools/ik_stamps.py); never in the shipped library
 #define GMR_STAMP(i) do { const u64 t_ = __builtin_readcyclecounter(); stamp_acc[i] += t_ - stamp_last; stamp_last = t_; } while (0)
+#elif defined(GMR_IK_MARKS)  // diagnostic: phase boundaries as comments in the ISA (tools/isa_regions.py --marks)
+#define GMR_STAMP(i) asm volatile("; gmr-mark " #i)
 #else
 #define GMR_STAMP(i) do { } while (0)
 #endif
@@ -637,7 +639,7 @@ __device__ __forceinline__ int box_qp(int lane, int n_act, const double *Hm, dou
 // lane keeps its raw row, which is what the back-substitution consumes.  16 registers per row instead of NVP.
 template <int K>
 __device__ __forceinline__ double group_bcast(double v) {  // value of lane (lane & 48) + K: one v_mov_b64_dpp row_newbcast, no LDS
-  return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xf, 0xf, false);
+  return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xf, 0xf, true);  // every lane has a source: no 'old' value to keep
 }
 // v summed over the four 16-lane groups (same local lane), result in every group: gfx950 v_permlane{16,32}_swap, no LDS.
 // permlane16_swap(x, x) leaves {rows 0,0,2,2} in the first operand and {rows 1,1,3,3} in the second; permlane32_swap the halves.
@@ -720,14 +722,17 @@ __device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool 
     auto step = [&](auto K) {
       constexpr int k = K;
       const double invd = fast_rcp(group_bcast<k>(R[k]));
-      const double u = a > k ? R[k] * invd : 0.0;
-      myinvd = a == k ? invd : myinvd;
       const double bk = group_bcast<k>(bb);
-      static_for<k + 1, 16>([&](auto J) {
-        constexpr int jj = J;
-        R[jj] -= u * group_bcast<jj>(R[k]);
-      });
-      bb -= u * bk;
+      if (a == k) { myinvd = invd; R[k] = 0.0; }
+      if (a > k) {  // rows below the pivot (their lanes are exactly the sources of the broadcasts inside)
+        const double u = R[k] * invd;
+        static_for<k + 1, 16>([&](auto J) {
+          constexpr int jj = J;
+          R[jj] -= u * group_bcast<jj>(R[k]);
+        });
+        bb -= u * bk;
+        R[k] = 0.0;  // dead from here; zero so that the back-substitution needs no triangle mask
+      }
     };
     static_for<0, 10>([&](auto K) { if (K < nl) step(K); });  // wave-uniform
 #else
@@ -772,12 +777,19 @@ __device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool 
       if (k >= nl) step(k);
 #endif
     // ---- back-substitution, k = 15 .. 0: x_k = (y_k - sum_{b>k} R_k[b] x_b) / d_k ----
+#if GMR_SQ_ELIM_DPP
+    static_for_down<0, 16>([&](auto K) {  // R[k] is 0 on and left of the diagonal (cleared by the elimination)
+      constexpr int k = K;
+      bb -= R[k] * group_bcast<k>(bb * myinvd);
+    });
+#else
     static_for_down<0, 16>([&](auto K) {
       constexpr int k = K;
       const double xk = group_bcast<k>(bb * myinvd);
       const double coef = a < k ? R[k] : 0.0;
       bb -= coef * xk;
     });
+#endif
     const double z = bb * myinvd;
     // ratio test along x -> z over the free variables (owner lanes only)
     double al = 2.0;

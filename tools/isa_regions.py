@@ -23,6 +23,11 @@ def main():
     region, regions = [], []
     for i in range(start, end):
         l = lines[i].strip()
+        if "gmr-mark" in l:
+            region.append((i, "mark", l))
+            regions.append(region)
+            region = []
+            continue
         if not l or l.startswith(";") or l.startswith(".") or l.endswith(":"):
             continue
         op = l.split()[0]
@@ -63,7 +68,8 @@ def main():
                     body = sum(1 for j, _, _ in reg if labels[tgt] <= j <= i)
                     loops.append(f"{tgt}:{body}")
         first = reg[0][0] + 1 if reg else -1
-        print(f"region {n:2d} @{first:6d} total {len(reg):5d}  valu {c['valu']:5d} (f64 {f64:5d})  salu {c['salu']:4d} smem {c['smem']:3d} lds {c['lds']:4d} "
+        tag = reg[-1][2] if reg and reg[-1][1] == "mark" else ""
+        print(f"region {n:2d} ends[{tag[-12:]:>12s}] @{first:6d} total {len(reg):5d}  valu {c['valu']:5d} (f64 {f64:5d})  salu {c['salu']:4d} smem {c['smem']:3d} lds {c['lds']:4d} "
               f"vmem {c['vmem']:3d} scratch {c['scratch']:3d} wait {c['wait']:4d} br {c['branch']:3d}  loops {' '.join(loops)}")
 
 
