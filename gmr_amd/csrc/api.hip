@@ -31,8 +31,8 @@ struct gmr_model {
   // device storage
   void *dev = nullptr;
   size_t dev_bytes = 0;
-  gmr::DevModel dm{};
-  const gmr::DevModel *dm_dev = nullptr;  // the same struct in device memory (kernels read it through scalar loads)
+  gmr::DevModel dm{};                      // host copy of the device model (scalars are read back by the host API)
+  const gmr::DevModel *dm_dev = nullptr;  // the struct in device memory: the one model argument of the IK kernels
   gmr::FkTree fk{};
   gmr::LdsLayout lay{};
   int nvp = 0, n_act = 0, lds_bytes = 0, fk_lds_bytes = 0;
@@ -123,10 +123,10 @@ int pick_nvp(int n_act) {
 template <int NVP>
 void launch_ik(const gmr_model *m, const gmr::IkLaunch &L, hipStream_t st) {
   if (m->dm.sq_ok && !m->force_generic)
-    hipLaunchKernelGGL((gmr::ik_kernel<NVP, true>), dim3(L.n_items), dim3(64), m->lds_bytes, st, m->dm, L, m->lay);
+    hipLaunchKernelGGL((gmr::ik_kernel<NVP, true>), dim3(L.n_items), dim3(64), m->lds_bytes, st, m->dm_dev, L, m->lay);
 #ifndef GMR_IK_DEV_ONLY36
   else
-    hipLaunchKernelGGL((gmr::ik_kernel<NVP, false>), dim3(L.n_items), dim3(64), m->lds_bytes, st, m->dm, L, m->lay);
+    hipLaunchKernelGGL((gmr::ik_kernel<NVP, false>), dim3(L.n_items), dim3(64), m->lds_bytes, st, m->dm_dev, L, m->lay);
 #endif
 }
 
@@ -535,16 +535,31 @@ int build_device_model(gmr_model *m) {
   std::vector<int> v_sfoot(blob_ptr<int32_t>(B, h.off_slot_is_foot), blob_ptr<int32_t>(B, h.off_slot_is_foot) + ns);
   abody.resize(64, 0); akind.resize(64, 0); aqadr.resize(64, 0); alim.resize(64, 0); arange.resize(128, 0.0);
 
+  gmr::DevModel &dm = m->dm;
+  dm = gmr::DevModel{};
+  dm.nbody = nb; dm.nq = nq; dm.nv = nv; dm.nslot = ns; dm.root_slot = h.root_slot; dm.maxdepth = maxdepth; dm.n_act = n_act;
+  for (int k = 0; k < 2; ++k) { dm.ntask[k] = h.ntask[k]; dm.use_table[k] = h.use_table[k] && h.ntask[k] > 0; dm.ncomp[k] = ncomp[k]; dm.ncpass[k] = ncpass[k]; }
+  dm.npair = (int)hpair.size(); dm.fkrounds = fkrounds; dm.sq_ok = sq_ok; dm.sq_nlimb = sq_nlimb;
+  bool fits = true;
+  auto put = [&](auto &dst, const auto &src) {  // vector -> fixed-capacity array of the device struct
+    using D = std::remove_reference_t<decltype(dst[0])>;
+    static_assert(sizeof(D) % sizeof(src[0]) == 0, "element size mismatch");
+    if (src.size() * sizeof(src[0]) > sizeof(dst)) { fits = false; return; }
+    if (!src.empty()) memcpy(&dst[0], src.data(), src.size() * sizeof(src[0]));
+  };
+  put(dm.parent, v_parent); put(dm.jtype, v_jtype); put(dm.qadr, v_qadr); put(dm.depth, depth);
+  put(dm.bpos, v_bpos); put(dm.bquat, v_bquat); put(dm.axis, v_axis); put(dm.qpos0, v_qpos0);
+  put(dm.sscale, v_sscale); put(dm.spoff, v_spoff); put(dm.sroff, v_sroff); put(dm.sfoot, v_sfoot);
+  put(dm.tbody, tbody); put(dm.tslot, tslot); put(dm.twp, twp); put(dm.twr, twr);
+  put(dm.abody, abody); put(dm.akind, akind); put(dm.aqadr, aqadr); put(dm.alimited, alim);
+  put(dm.aanc, aanc); put(dm.arange, arange); put(dm.acomp, acomp); put(dm.compmask, compmask);
+  put(dm.hpair, hpair); put(dm.fkanc, fkanc); put(dm.comp_plan, comp_plan);
+  put(dm.sq_gdof, sq_gdof); put(dm.sq_owner, sq_owner); put(dm.sq_lane_of_dof, sq_lane_of_dof); put(dm.sq_diag, sq_diag); put(dm.sq_dst, sq_dst);
+  if (!fits) { set_err(m, "internal: a model table exceeds its fixed capacity"); return GMR_EUNSUPPORTED; }
+
   Packer P;
-  const size_t o_parent = P.add(v_parent), o_jtype = P.add(v_jtype), o_qadr = P.add(v_qadr), o_depth = P.add(depth);
-  const size_t o_bpos = P.add(v_bpos), o_bquat = P.add(v_bquat), o_axis = P.add(v_axis), o_qpos0 = P.add(v_qpos0);
-  const size_t o_sscale = P.add(v_sscale), o_spoff = P.add(v_spoff), o_sroff = P.add(v_sroff), o_sfoot = P.add(v_sfoot);
-  const size_t o_tbody = P.add(tbody), o_tslot = P.add(tslot), o_twp = P.add(twp), o_twr = P.add(twr);
-  const size_t o_abody = P.add(abody), o_akind = P.add(akind), o_aqadr = P.add(aqadr), o_alim = P.add(alim);
-  const size_t o_aanc = P.add(aanc), o_arange = P.add(arange), o_acomp = P.add(acomp), o_compmask = P.add(compmask);
-  const size_t o_hpair = P.add(hpair), o_fkanc = P.add(fkanc), o_cplan = P.add(comp_plan);
-  const size_t o_sqg = P.add(sq_gdof), o_sqo = P.add(sq_owner), o_sql = P.add(sq_lane_of_dof), o_sqd = P.add(sq_diag), o_sqdst = P.add(sq_dst);
   const size_t o_dm = P.add(std::vector<gmr::DevModel>(1));
+  const size_t o_parent = P.add(v_parent);
   const size_t o_dofidx = P.add(dofidx), o_src = P.add(src_slot), o_save = P.add(save_slot);
   const size_t o_lpos = P.add(lpos), o_lrot = P.add(lrot), o_jaxis = P.add(jaxis), o_jaxis64 = P.add(jaxis64);
 
@@ -552,18 +567,6 @@ int build_device_model(gmr_model *m) {
   m->dev_bytes = P.buf.size();
   const uint8_t *D = static_cast<const uint8_t *>(m->dev);
 #define DP(T, off) reinterpret_cast<const T *>(D + (off))
-  gmr::DevModel &dm = m->dm;
-  dm.nbody = nb; dm.nq = nq; dm.nv = nv; dm.nslot = ns; dm.root_slot = h.root_slot; dm.maxdepth = maxdepth; dm.n_act = n_act;
-  for (int k = 0; k < 2; ++k) { dm.ntask[k] = h.ntask[k]; dm.use_table[k] = h.use_table[k] && h.ntask[k] > 0; dm.ncomp[k] = ncomp[k]; }
-  dm.parent = DP(int, o_parent); dm.jtype = DP(int, o_jtype); dm.qadr = DP(int, o_qadr); dm.depth = DP(int, o_depth);
-  dm.bpos = DP(double, o_bpos); dm.bquat = DP(double, o_bquat); dm.axis = DP(double, o_axis); dm.qpos0 = DP(double, o_qpos0);
-  dm.sscale = DP(double, o_sscale); dm.spoff = DP(double, o_spoff); dm.sroff = DP(double, o_sroff); dm.sfoot = DP(int, o_sfoot);
-  dm.tbody = DP(int, o_tbody); dm.tslot = DP(int, o_tslot); dm.twp = DP(double, o_twp); dm.twr = DP(double, o_twr);
-  dm.abody = DP(int, o_abody); dm.akind = DP(int, o_akind); dm.aqadr = DP(int, o_aqadr); dm.alimited = DP(int, o_alim);
-  dm.aanc = DP(u64, o_aanc); dm.arange = DP(double, o_arange); dm.acomp = DP(int, o_acomp); dm.compmask = DP(unsigned, o_compmask);
-  dm.hpair = DP(unsigned short, o_hpair); dm.comp_plan = DP(uint4, o_cplan); dm.ncpass[0] = ncpass[0]; dm.ncpass[1] = ncpass[1]; dm.npair = (int)hpair.size(); dm.fkanc = DP(u64, o_fkanc); dm.fkrounds = fkrounds;
-  dm.sq_gdof = DP(signed char, o_sqg); dm.sq_owner = DP(signed char, o_sqo); dm.sq_lane_of_dof = DP(int, o_sql); dm.sq_diag = DP(int, o_sqd);
-  dm.sq_dst = DP(unsigned, o_sqdst); dm.sq_ok = sq_ok; dm.sq_nlimb = sq_nlimb;
   m->dm_dev = DP(gmr::DevModel, o_dm);
   gmr::FkTree &fk = m->fk;
   fk.parent = DP(int, o_parent); fk.dofidx = DP(int, o_dofidx); fk.src_slot = DP(int, o_src); fk.save_slot = DP(int, o_save);
@@ -836,7 +839,7 @@ int gmr_evaluate(gmr_model *m, const double *qpos, int64_t n_frames, const void 
     L.hpos = human_pos; L.hquat = human_quat; L.slot_col = static_cast<const int *>(m->ws);
     L.in_f64 = in_dtype == GMR_DTYPE_F64; L.n_cols = n_cols;
   }
-  hipLaunchKernelGGL(gmr::eval_kernel, dim3((unsigned)n_frames), dim3(64), m->lds_bytes, st, m->dm, L, m->lay);
+  hipLaunchKernelGGL(gmr::eval_kernel, dim3((unsigned)n_frames), dim3(64), m->lds_bytes, st, m->dm_dev, L, m->lay);
   HIP_TRY(m, hipGetLastError());
   return GMR_OK;
 }

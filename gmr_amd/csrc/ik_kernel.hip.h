@@ -74,35 +74,37 @@ constexpr int kBT = 27;  // doubles per task block: LL(6) LA(9) AA(6) g(6)
 constexpr int kMaxCompPass = 32;  // passes of the composite plan (two composites per pass, children before parents)
 constexpr double kLieEps = 1e-10;  // mink.lie.utils.get_epsilon(float64)
 
-// Device view of a compiled model: pointers into one device allocation (see api.hip).
+// A compiled model as the kernels see it: ONE struct of fixed-capacity arrays in device memory (filled by api.hip), reached
+// through a single kernel-argument pointer.  Every table is base + compile-time offset, so the model costs two SGPRs instead
+// of two per table (with ~45 tables passed by value the kernel spilled hundreds of SGPRs into VGPR lanes).
+constexpr int kMaxPairs = GMR_MAX_BODIES * (GMR_MAX_BODIES - 1) / 2;
 struct DevModel {
   int nbody, nq, nv, nslot, root_slot, maxdepth, n_act, pad0;
-  int ntask[2], use_table[2], ncomp[2];
-  // per body [nbody]
-  const int *parent, *jtype, *qadr, *depth;
-  const double *bpos, *bquat, *axis;  // [nb][3], [nb][4] unit wxyz, [nb][3]
-  const double *qpos0;                // [nq]
-  // per slot [nslot]
-  const double *sscale, *spoff, *sroff;
-  const int *sfoot;
-  // per task, table-major [2][GMR_MAX_TASKS]
-  const int *tbody, *tslot;
-  const double *twp, *twr;
-  // per active dof [64]
-  const int *abody, *akind, *aqadr, *alimited;  // akind: 0..2 root translation, 3..5 root rotation, 6 hinge
-  const u64 *aanc;                              // active dofs strictly above (lower index)
-  const double *arange;                         // [64][2]
-  const int *acomp;                             // [2][64] composite node of the dof per table
-  const unsigned *compmask;                     // [2][GMR_MAX_TASKS*2] tasks summed into each composite
-  const unsigned short *hpair;                  // [npair] (i << 8) | j for every dof j strictly above dof i
-  const u64 *fkanc;                             // [nbody] byte r = ancestor folded in FK round r (0xff: none)
-  const uint4 *comp_plan;                       // [2][kMaxCompPass][64] per pass and lane: LDS byte offsets {s0|s1<<16, s2|s3<<16, dst, -}
-  int ncpass[2];                                // composite passes per table
-  // structured QP (box_qp_struct): 4 groups of 16 lanes, each = one bin of limb dofs + a copy of the core dofs
-  const signed char *sq_gdof, *sq_owner;        // [64] dof of a structured lane (-1 padding); 1 if the lane owns that dof
-  const int *sq_lane_of_dof, *sq_diag;          // [64] per dof: its owner lane; LDS index of its diagonal entry
-  const unsigned *sq_dst;                       // [npair] the two LDS indices (lo/hi 16 bits) an H pair is written to
+  int ntask[2], use_table[2], ncomp[2], ncpass[2];  // ncpass: composite passes per table
   int npair, fkrounds, sq_ok, sq_nlimb;
+  // per active dof [64]
+  int abody[64], akind[64], aqadr[64], alimited[64];  // akind: 0..2 root translation, 3..5 root rotation, 6 hinge
+  double arange[128];                                 // [64][2]
+  int acomp[2 * 64];                                  // composite node of the dof per table
+  u64 aanc[64];                                       // active dofs strictly above (lower index)
+  // per task, table-major [2][GMR_MAX_TASKS]
+  int tbody[2 * GMR_MAX_TASKS], tslot[2 * GMR_MAX_TASKS];
+  double twp[2 * GMR_MAX_TASKS], twr[2 * GMR_MAX_TASKS];
+  // per body [nbody]
+  int parent[GMR_MAX_BODIES], jtype[GMR_MAX_BODIES], qadr[GMR_MAX_BODIES], depth[GMR_MAX_BODIES];
+  double bpos[3 * GMR_MAX_BODIES], bquat[4 * GMR_MAX_BODIES], axis[3 * GMR_MAX_BODIES];  // bquat: unit wxyz
+  u64 fkanc[GMR_MAX_BODIES];                          // byte r = ancestor folded in FK round r (0xff: none)
+  double qpos0[GMR_MAX_BODIES + 8];                   // [nq]
+  // per slot [nslot]
+  double sscale[GMR_MAX_SLOTS], spoff[3 * GMR_MAX_SLOTS], sroff[4 * GMR_MAX_SLOTS];
+  int sfoot[GMR_MAX_SLOTS];
+  unsigned compmask[2 * 2 * GMR_MAX_TASKS];           // tasks summed into each composite
+  // structured QP (box_qp_struct): 4 groups of 16 lanes, each = one bin of limb dofs + a copy of the core dofs
+  signed char sq_gdof[64], sq_owner[64];              // dof of a structured lane (-1 padding); 1 if the lane owns that dof
+  int sq_lane_of_dof[64], sq_diag[64];                // per dof: its owner lane; LDS index of its diagonal entry
+  unsigned short hpair[kMaxPairs];                    // [npair] (i << 8) | j for every dof j strictly above dof i
+  unsigned sq_dst[kMaxPairs];                         // [npair] the two LDS indices (lo/hi 16 bits) an H pair is written to
+  uint4 comp_plan[2 * kMaxCompPass * 64];             // per pass and lane: LDS byte offsets {s0|s1<<16, s2|s3<<16, dst, -}
 };
 
 struct LdsLayout {
@@ -838,7 +840,8 @@ __device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool 
 
 // ------------------------------------------------------------------ the kernel
 template <int NVP, bool SQ>
-__global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const DevModel m, IkLaunch L, LdsLayout lay) {
+__global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const DevModel *__restrict__ mp, IkLaunch L, LdsLayout lay) {
+  const DevModel &m = *mp;
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
   double *q = lds + lay.q, *xpos = lds + lay.xpos, *xquat = lds + lay.xquat, *tp = lds + lay.tp, *tq = lds + lay.tq;
@@ -1162,7 +1165,8 @@ struct EvalLaunch {
   long long n_frames;
 };
 
-__global__ void __launch_bounds__(64) eval_kernel(const DevModel m, EvalLaunch L, LdsLayout lay) {
+__global__ void __launch_bounds__(64) eval_kernel(const DevModel *__restrict__ mp, EvalLaunch L, LdsLayout lay) {
+  const DevModel &m = *mp;
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
   const long long f = blockIdx.x;
