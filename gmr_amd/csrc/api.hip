@@ -500,6 +500,22 @@ int build_device_model(gmr_model *m) {
     }
     ncpass[k] = pass;
   }
+  // ---- H assembly plan: per pair the LDS byte offsets of S_j, F_i and of the two entries of H it fills ----
+  std::vector<uint32_t> hplan;
+  {
+    const gmr::LdsLayout &Ly = m->lay;
+    const int hsize = sq ? 1024 : nvp * nvp;  // the two doubles after H are the dummy slots of the padding entries
+    for (size_t p = 0; p < hpair.size(); ++p) {
+      const int i = hpair[p] >> 8, j = hpair[p] & 0xff;
+      const unsigned d0 = sq ? (sq_dst[p] & 0xffffu) : (unsigned)(j * nvp + i), d1 = sq ? (sq_dst[p] >> 16) : (unsigned)(i * nvp + j);
+      hplan.push_back((uint32_t)((Ly.S + 6 * j) * 8) | ((uint32_t)((Ly.F + 6 * i) * 8) << 16));
+      hplan.push_back((uint32_t)((Ly.H + (int)d0) * 8) | ((uint32_t)((Ly.H + (int)d1) * 8) << 16));
+    }
+    while ((hplan.size() / 2) % 64 != 0) {
+      hplan.push_back((uint32_t)(Ly.S * 8) | ((uint32_t)(Ly.F * 8) << 16));
+      hplan.push_back((uint32_t)((Ly.H + hsize) * 8) | ((uint32_t)((Ly.H + hsize + 1) * 8) << 16));
+    }
+  }
   // ---- FK (KinematicsModel convention) tables and branch-slot plan ----
   std::vector<int> dofidx(nb, -1), src_slot(nb, -1), save_slot(nb, -1), last_child(nb, -1), nchild_other(nb, 0);
   std::vector<float> lpos(3 * nb), lrot(4 * nb), jaxis(3 * nb);
@@ -539,7 +555,7 @@ int build_device_model(gmr_model *m) {
   dm = gmr::DevModel{};
   dm.nbody = nb; dm.nq = nq; dm.nv = nv; dm.nslot = ns; dm.root_slot = h.root_slot; dm.maxdepth = maxdepth; dm.n_act = n_act;
   for (int k = 0; k < 2; ++k) { dm.ntask[k] = h.ntask[k]; dm.use_table[k] = h.use_table[k] && h.ntask[k] > 0; dm.ncomp[k] = ncomp[k]; dm.ncpass[k] = ncpass[k]; }
-  dm.npair = (int)hpair.size(); dm.fkrounds = fkrounds; dm.sq_ok = sq_ok; dm.sq_nlimb = sq_nlimb;
+  dm.npairp = (int)hplan.size() / 2; dm.fkrounds = fkrounds; dm.sq_ok = sq_ok; dm.sq_nlimb = sq_nlimb;
   bool fits = true;
   auto put = [&](auto &dst, const auto &src) {  // vector -> fixed-capacity array of the device struct
     using D = std::remove_reference_t<decltype(dst[0])>;
@@ -553,8 +569,8 @@ int build_device_model(gmr_model *m) {
   put(dm.tbody, tbody); put(dm.tslot, tslot); put(dm.twp, twp); put(dm.twr, twr);
   put(dm.abody, abody); put(dm.akind, akind); put(dm.aqadr, aqadr); put(dm.alimited, alim);
   put(dm.aanc, aanc); put(dm.arange, arange); put(dm.acomp, acomp); put(dm.compmask, compmask);
-  put(dm.hpair, hpair); put(dm.fkanc, fkanc); put(dm.comp_plan, comp_plan);
-  put(dm.sq_gdof, sq_gdof); put(dm.sq_owner, sq_owner); put(dm.sq_lane_of_dof, sq_lane_of_dof); put(dm.sq_diag, sq_diag); put(dm.sq_dst, sq_dst);
+  put(dm.hplan, hplan); put(dm.fkanc, fkanc); put(dm.comp_plan, comp_plan);
+  put(dm.sq_gdof, sq_gdof); put(dm.sq_owner, sq_owner); put(dm.sq_lane_of_dof, sq_lane_of_dof); put(dm.sq_diag, sq_diag);
   if (!fits) { set_err(m, "internal: a model table exceeds its fixed capacity"); return GMR_EUNSUPPORTED; }
 
   Packer P;

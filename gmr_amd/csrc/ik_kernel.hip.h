@@ -77,11 +77,11 @@ constexpr double kLieEps = 1e-10;  // mink.lie.utils.get_epsilon(float64)
 // A compiled model as the kernels see it: ONE struct of fixed-capacity arrays in device memory (filled by api.hip), reached
 // through a single kernel-argument pointer.  Every table is base + compile-time offset, so the model costs two SGPRs instead
 // of two per table (with ~45 tables passed by value the kernel spilled hundreds of SGPRs into VGPR lanes).
-constexpr int kMaxPairs = GMR_MAX_BODIES * (GMR_MAX_BODIES - 1) / 2;
+constexpr int kMaxPairsPadded = (GMR_MAX_BODIES * (GMR_MAX_BODIES - 1) / 2 + 63) / 64 * 64;
 struct DevModel {
   int nbody, nq, nv, nslot, root_slot, maxdepth, n_act, pad0;
   int ntask[2], use_table[2], ncomp[2], ncpass[2];  // ncpass: composite passes per table
-  int npair, fkrounds, sq_ok, sq_nlimb;
+  int npairp, fkrounds, sq_ok, sq_nlimb;              // npairp: entries of hplan (a multiple of 64)
   // per active dof [64]
   int abody[64], akind[64], aqadr[64], alimited[64];  // akind: 0..2 root translation, 3..5 root rotation, 6 hinge
   double arange[128];                                 // [64][2]
@@ -102,8 +102,9 @@ struct DevModel {
   // structured QP (box_qp_struct): 4 groups of 16 lanes, each = one bin of limb dofs + a copy of the core dofs
   signed char sq_gdof[64], sq_owner[64];              // dof of a structured lane (-1 padding); 1 if the lane owns that dof
   int sq_lane_of_dof[64], sq_diag[64];                // per dof: its owner lane; LDS index of its diagonal entry
-  unsigned short hpair[kMaxPairs];                    // [npair] (i << 8) | j for every dof j strictly above dof i
-  unsigned sq_dst[kMaxPairs];                         // [npair] the two LDS indices (lo/hi 16 bits) an H pair is written to
+  // H assembly plan, one entry per structurally non-zero off-diagonal pair (dof j strictly above dof i), padded to a multiple
+  // of 64 with entries that land in the dummy slots: LDS byte offsets {S_j | F_i << 16, H[i][j] | H[j][i] << 16}
+  uint2 hplan[kMaxPairsPadded];
   uint4 comp_plan[2 * kMaxCompPass * 64];             // per pass and lane: LDS byte offsets {s0|s1<<16, s2|s3<<16, dst, -}
 };
 
@@ -846,7 +847,6 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
   const int lane = threadIdx.x;
   double *q = lds + lay.q, *xpos = lds + lay.xpos, *xquat = lds + lay.xquat, *tp = lds + lay.tp, *tq = lds + lay.tq;
   double *Bt = lds + lay.B, *Bc = lds + lay.Bc, *S = lds + lay.S, *F = lds + lay.F, *Hm = lds + lay.H;
-  const unsigned short *pairs = m.hpair;  // read through L2 each solve (laundered index)
   double *bodyc = lay.bodyc >= 0 ? lds + lay.bodyc : nullptr;
   if (bodyc) stage_tree(m, lane, bodyc);
   if (lane == 0) lds[lay.zero] = 0.0;  // the composite plan's "absent block" (never aliased); lds[lay.zero + 1] absorbs idle lanes' writes
@@ -856,7 +856,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
   u64 stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   u64 stamp_last = __builtin_readcyclecounter();
 #endif
-  const int nq = m.nq, n_act = m.n_act, nslot = m.nslot, root_slot = m.root_slot, npair = m.npair, nbody = m.nbody, fkrounds = m.fkrounds;
+  const int nq = m.nq, n_act = m.n_act, nslot = m.nslot, root_slot = m.root_slot, npairp = m.npairp, nbody = m.nbody, fkrounds = m.fkrounds;
   // active-dof constants of this lane (row of the QP); the rest is re-read where it is used
   const bool real_row = lane < n_act;
   const int arow = real_row ? lane : 0;
@@ -1021,31 +1021,32 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         __syncthreads();  // Bc / poses are dead from here: H overwrites them
         GMR_STAMP(6);
         // ---- H into LDS: zero fill, then the structurally non-zero pairs spread over all lanes ----
+        // every structurally non-zero off-diagonal pair (i below j): H[i][j] = H[j][i] = S_j . F_i, spread over all lanes by a
+        // host-made plan of LDS byte offsets (padding entries land in the dummy slots)
+        auto h_pairs = [&]() {
+          char *lb = reinterpret_cast<char *>(lds);
+          uint2 pl[kPairRounds];
+#pragma unroll
+          for (int r = 0; r < kPairRounds; r++)
+            if (64 * r < npairp) pl[r] = m.hplan[launder(lane + 64 * r)];  // wave-uniform guard
+#pragma unroll
+          for (int r = 0; r < kPairRounds; r++) {
+            if (64 * r < npairp) {
+              const double2 *Sj = reinterpret_cast<const double2 *>(lb + (pl[r].x & 0xffffu)), *Fi = reinterpret_cast<const double2 *>(lb + (pl[r].x >> 16));
+              const double2 s0 = Sj[0], s1 = Sj[1], s2 = Sj[2], f0 = Fi[0], f1 = Fi[1], f2 = Fi[2];
+              const double d = s0.x * f0.x + s0.y * f0.y + s1.x * f1.x + s1.y * f1.y + s2.x * f2.x + s2.y * f2.y;
+              *reinterpret_cast<double *>(lb + (pl[r].y & 0xffffu)) = d;
+              *reinterpret_cast<double *>(lb + (pl[r].y >> 16)) = d;
+            }
+          }
+        };
         double dq;
         int qit;
         if constexpr (SQ) {
           // structured layout Hs[col * 64 + lane]: every pair lands in the (at most two) rows that carry it
-          for (int idx = lane; idx < 1024; idx += 64) Hm[idx] = 0.0;  // same wave: LDS keeps program order, no barrier needed
-          GMR_DUP(7) {
-            int prs[kPairRounds];
-            unsigned dst[kPairRounds];
 #pragma unroll
-            for (int r = 0; r < kPairRounds; r++) {
-              const int pi = launder(lane + 64 * r);
-              prs[r] = pi < npair ? (int)pairs[pi] : -1;
-              dst[r] = pi < npair ? m.sq_dst[pi] : 0u;
-            }
-#pragma unroll
-            for (int r = 0; r < kPairRounds; r++) {
-              if (64 * r < npair) {  // wave-uniform
-                const int pr = prs[r], i = pr >= 0 ? pr >> 8 : 0, j = pr >= 0 ? pr & 0xff : 0;
-                const double *Sj = S + 6 * j, *Fi = F + 6 * i;
-                const double d = Sj[0] * Fi[0] + Sj[1] * Fi[1] + Sj[2] * Fi[2] + Sj[3] * Fi[3] + Sj[4] * Fi[4] + Sj[5] * Fi[5];
-                Hm[pr >= 0 ? (int)(dst[r] & 0xffffu) : 1024] = d;  // unused lanes hit the dummy slot
-                Hm[pr >= 0 ? (int)(dst[r] >> 16) : 1025] = d;
-              }
-            }
-          }
+          for (int i = 0; i < 16; i++) Hm[i * 64 + lane] = 0.0;  // same wave: LDS keeps program order, no barrier needed
+          GMR_DUP(7) h_pairs();
           if (real_row) {
             const double *Fi = F + 6 * lane;
             Hm[sq_mydiag] = Si[0] * Fi[0] + Si[1] * Fi[1] + Si[2] * Fi[2] + Si[3] * Fi[3] + Si[4] * Fi[4] + Si[5] * Fi[5] + diag;
@@ -1072,22 +1073,10 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
           __syncthreads();
           dq = real_row ? V[lane] : 0.0;
         } else {
-          for (int idx = lane; idx < NVP * NVP; idx += 64) Hm[idx] = 0.0;  // same wave: LDS keeps program order, no barrier needed
-          {
-            int prs[kPairRounds];
 #pragma unroll
-            for (int r = 0; r < kPairRounds; r++) prs[r] = lane + 64 * r < npair ? (int)pairs[launder(lane + 64 * r)] : -1;
-#pragma unroll
-            for (int r = 0; r < kPairRounds; r++) {  // H[i][j] = S_j . F_i for every dof j above i (and the mirror)
-              if (64 * r < npair) {  // wave-uniform
-                const int pr = prs[r], i = pr >= 0 ? pr >> 8 : 0, j = pr >= 0 ? pr & 0xff : 0;
-                const double *Sj = S + 6 * j, *Fi = F + 6 * i;
-                const double d = Sj[0] * Fi[0] + Sj[1] * Fi[1] + Sj[2] * Fi[2] + Sj[3] * Fi[3] + Sj[4] * Fi[4] + Sj[5] * Fi[5];
-                Hm[pr >= 0 ? j * NVP + i : NVP * NVP] = d;       // unused lanes hit the dummy slot
-                Hm[pr >= 0 ? i * NVP + j : NVP * NVP + 1] = d;
-              }
-            }
-          }
+          for (int i = 0; i < (NVP * NVP + 63) / 64; i++)
+            if (i * 64 + lane < NVP * NVP) Hm[i * 64 + lane] = 0.0;  // same wave: LDS keeps program order, no barrier needed
+          h_pairs();
           if (lane < NVP) {
             const double *Fi = F + 6 * lane;
             Hm[lane * NVP + lane] = real_row ? Si[0] * Fi[0] + Si[1] * Fi[1] + Si[2] * Fi[2] + Si[3] * Fi[3] + Si[4] * Fi[4] + Si[5] * Fi[5] + diag : 1.0;
