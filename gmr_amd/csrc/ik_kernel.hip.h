@@ -130,6 +130,12 @@ __device__ __forceinline__ int launder(int v) {
   asm volatile("" : "+v"(v));
   return v;
 }
+// Same for a wave-uniform value (stays in an SGPR): conditions on it are re-evaluated where they are used instead of being
+// hoisted out of the loop as a set of long-lived lane masks.
+__device__ __forceinline__ int launder_uniform(int v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
 
 // ------------------------------------------------------------------ wave helpers (wave = 64)
 __device__ __forceinline__ double rdlane(double v, int lane) {  // lane: wave-uniform
@@ -726,8 +732,9 @@ __device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool 
       constexpr int k = K;
       const double invd = fast_rcp(group_bcast<k>(R[k]));
       const double bk = group_bcast<k>(bb);
-      if (a == k) { myinvd = invd; R[k] = 0.0; }
-      if (a > k) {  // rows below the pivot (their lanes are exactly the sources of the broadcasts inside)
+      const int ak = launder(a);  // compare here, per step: 32 lane masks hoisted out of the loop would cost 64 SGPRs
+      if (ak == k) { myinvd = invd; R[k] = 0.0; }
+      if (ak > k) {  // rows below the pivot (their lanes are exactly the sources of the broadcasts inside)
         const double u = R[k] * invd;
         static_for<k + 1, 16>([&](auto J) {
           constexpr int jj = J;
@@ -737,7 +744,8 @@ __device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool 
         R[k] = 0.0;  // dead from here; zero so that the back-substitution needs no triangle mask
       }
     };
-    static_for<0, 10>([&](auto K) { if (K < nl) step(K); });  // wave-uniform
+    static_for<0, 6>([&](auto K) { step(K); });  // nl >= 6 (the core has at most 10 dofs)
+    static_for<6, 10>([&](auto K) { if (K < launder_uniform(nl)) step(K); });  // wave-uniform scalar branch
 #else
     auto step = [&](const int k) {
       Cc[lane] = R[k];  // = H^(k)[a][k] = H^(k)[k][a]
@@ -762,18 +770,17 @@ __device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool 
 #endif
     // every copy of the core block / rhs <- sum over the four groups
 #pragma unroll
-    for (int b = 6; b < 16; b++) {
-      if (b >= nl) {
-        const double t = group_sum4(R[b]);
-        R[b] = core_row ? t : R[b];
-      }
+    for (int b = 6; b < 16; b++) {  // columns 6 .. nl-1 are limb columns: already zero in the core rows, summing them is harmless
+      const double t = group_sum4(R[b]);
+      R[b] = core_row ? t : R[b];
     }
     {
       const double t = group_sum4(bb);
       bb = core_row ? t : bb;
     }
 #if GMR_SQ_ELIM_DPP
-    static_for<6, 16>([&](auto K) { if (K >= nl) step(K); });
+    static_for<6, 10>([&](auto K) { if (K >= launder_uniform(nl)) step(K); });
+    static_for<10, 16>([&](auto K) { step(K); });
 #else
 #pragma unroll
     for (int k = 6; k < 16; k++)
