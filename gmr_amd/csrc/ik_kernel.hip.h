@@ -801,17 +801,17 @@ __device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool 
     });
 #endif
     const double z = bb * myinvd;
-    // ratio test along x -> z over the free variables (owner lanes only)
-    double al = 2.0;
+    // ratio test along x -> z over the free variables (owner lanes only).  Usually nothing blocks: decide that with compares
+    // and one ballot, and only then pay for the divisions and the wave minimum.
     int side = 0;
     const bool freev = owner && status == 0;
     if (freev) {
-      const double d = z - x;
-      if (z > hi + 1e-14 && d > 0) { al = (hi - x) / d; side = 2; }
-      else if (z < lo - 1e-14 && d < 0) { al = (lo - x) / d; side = 1; }
+      if (z > hi + 1e-14 && z - x > 0) side = 2;
+      else if (z < lo - 1e-14 && z - x < 0) side = 1;
     }
-    const double amin = wave_min(al);
-    if (amin <= 1.0) {
+    if (__ballot(side != 0)) {  // wave-uniform
+      const double al = side ? ((side == 2 ? hi : lo) - x) / (z - x) : 2.0;
+      const double amin = wave_min(al);
       const u64 who = __ballot(al == amin);
       const int blk = (int)__builtin_ctzll(who);
       const double ac = fmax(amin, 0.0);
