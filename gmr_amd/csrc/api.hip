@@ -413,7 +413,9 @@ int build_device_model(gmr_model *m) {
   gmr::LdsLayout &L = m->lay;  // (named L here; the composite plan below needs the byte offsets)
   auto even = [](int x) { return (x + 1) & ~1; };
   int o = 0;
-  L.zero = o; o += 2;  // [0] stays 0.0 (absent block of the composite plan), [1] absorbs idle lanes' writes
+  L.zero = o; o += gmr::kBT + 1;  // a block of zeros: the absent sources of the composite plan (never aliased)
+  const int npairp_host = ((int)hpair.size() + 63) / 64 * 64;
+  L.hplan = o; o += npairp_host;  // H pair plan, 8 bytes per entry (staged once per wavefront)
   L.q = o; o += even(nq);
   L.tp = o; o += even(3 * ns);
   L.tq = o; o += 4 * ns;
@@ -425,13 +427,14 @@ int build_device_model(gmr_model *m) {
   const int bt = even(gmr::kBT * ntmax), px = std::max(even(7 * nb), even(gmr::kBT * ncmax));
   L.xpos = o + bt; L.xquat = L.xpos + even(3 * nb); L.Bc = o + bt;
   o += std::max(bt + px, (sq ? 1024 : nvp * nvp) + 2);  // + a dummy slot for the unused lanes of the pair rounds
+  L.cplan = o;  // composite plan, 16 bytes per (table, pass, half-wave); sized once the passes are scheduled (below)
   L.total_doubles = o;
   m->lds_bytes = o * (int)sizeof(double);
   m->nvp = nvp;
   m->n_act = n_act;
   // ---- composite plan: passes of <= 2 entries, an entry = one composite summed from <= 4 blocks, children before parents ----
   if (m->lds_bytes > 65535) { set_err(m, "model needs %d bytes of LDS per wavefront (plan offsets are 16 bit)", m->lds_bytes); return GMR_EUNSUPPORTED; }
-  std::vector<uint32_t> comp_plan((size_t)2 * gmr::kMaxCompPass * 64 * 4, 0u);
+  std::vector<uint32_t> comp_plan((size_t)2 * gmr::kMaxCompPass * 2 * 4, 0u);
   int ncpass[2] = {0, 0};
   for (int k = 0; k < 2; ++k) {
     struct Entry { int dst; std::vector<int> src; std::vector<int> deps; int done_pass = -1; int height = 0; };
@@ -439,13 +442,10 @@ int build_device_model(gmr_model *m) {
     std::vector<Entry> ent;
     std::vector<int> last_entry_of_comp(ncomp[k], -1);
     for (int c = 0; c < ncomp[k]; ++c) {
-      std::vector<int> srcs, deps;
+      std::vector<int> srcs;
       for (unsigned own = comp_own[k * 32 + c]; own; own &= own - 1) srcs.push_back(__builtin_ctz(own));
-      for (unsigned kids = comp_kids[k * 32 + c]; kids; kids &= kids - 1) {
-        const int d = __builtin_ctz(kids);
-        srcs.push_back(64 + d);
-      }
-      // children first in the source list of the *last* entry would lengthen the chain; put finished-early blocks (tasks) last
+      for (unsigned kids = comp_kids[k * 32 + c]; kids; kids &= kids - 1) srcs.push_back(64 + __builtin_ctz(kids));
+      // child composites first: the entries that wait for them should be few
       std::stable_sort(srcs.begin(), srcs.end(), [](int a, int b) { return (a >= 64) > (b >= 64); });
       size_t i = 0;
       bool first = true;
@@ -468,7 +468,7 @@ int build_device_model(gmr_model *m) {
     for (int i = ne - 1; i >= 0; --i)
       for (int d : ent[i].deps) ent[d].height = std::max(ent[d].height, ent[i].height + 1);
     int done = 0, pass = 0;
-    const int boff = m->lay.B * 8, coff = m->lay.Bc * 8, zoff = m->lay.zero * 8;
+    const int boff = m->lay.B * 8, coff = m->lay.Bc * 8, zoff = m->lay.zero * 8, scratch = m->lay.F * 8;  // F is dead during this phase
     auto block_off = [&](int id) { return id >= 64 ? coff + gmr::kBT * 8 * (id - 64) : boff + gmr::kBT * 8 * id; };
     while (done < ne) {
       if (pass >= gmr::kMaxCompPass) { set_err(m, "composite plan of table %d needs more than %d passes", k + 1, gmr::kMaxCompPass); return GMR_EUNSUPPORTED; }
@@ -484,15 +484,15 @@ int build_device_model(gmr_model *m) {
         pick[slot] = best;
       }
       if (pick[0] < 0) { set_err(m, "internal: composite plan stalled"); return GMR_EINVAL; }
-      uint32_t *row = comp_plan.data() + ((size_t)(k * gmr::kMaxCompPass + pass) * 64) * 4;
-      for (int lane = 0; lane < 64; ++lane) {
-        const int half = lane >> 5, el = lane & 31, ei = pick[half];
-        uint32_t so[4] = {(uint32_t)zoff, (uint32_t)zoff, (uint32_t)zoff, (uint32_t)zoff}, dst = (uint32_t)zoff + 8;
-        if (ei >= 0 && el < gmr::kBT) {
-          for (size_t j = 0; j < ent[ei].src.size(); ++j) so[j] = (uint32_t)(block_off(ent[ei].src[j]) + 8 * el);
-          dst = (uint32_t)(block_off(ent[ei].dst) + 8 * el);
+      for (int half = 0; half < 2; ++half) {
+        uint32_t *row = comp_plan.data() + ((size_t)(k * gmr::kMaxCompPass + pass) * 2 + half) * 4;
+        const int ei = pick[half];
+        uint32_t so[4] = {(uint32_t)zoff, (uint32_t)zoff, (uint32_t)zoff, (uint32_t)zoff}, dst = (uint32_t)scratch;
+        if (ei >= 0) {
+          for (size_t j = 0; j < ent[ei].src.size(); ++j) so[j] = (uint32_t)block_off(ent[ei].src[j]);
+          dst = (uint32_t)block_off(ent[ei].dst);
         }
-        row[4 * lane + 0] = so[0] | (so[1] << 16); row[4 * lane + 1] = so[2] | (so[3] << 16); row[4 * lane + 2] = dst; row[4 * lane + 3] = 0;
+        row[0] = so[0] | (so[1] << 16); row[1] = so[2] | (so[3] << 16); row[2] = dst; row[3] = 0;
       }
       for (int slot = 0; slot < 2; ++slot)
         if (pick[slot] >= 0) { ent[pick[slot]].done_pass = pass; ++done; }
@@ -500,6 +500,9 @@ int build_device_model(gmr_model *m) {
     }
     ncpass[k] = pass;
   }
+  m->lay.total_doubles += 4 * (ncpass[0] + ncpass[1]);
+  m->lds_bytes = m->lay.total_doubles * (int)sizeof(double);
+  if (m->lds_bytes > 65535) { set_err(m, "model needs %d bytes of LDS per wavefront (plan offsets are 16 bit)", m->lds_bytes); return GMR_EUNSUPPORTED; }
   // ---- H assembly plan: per pair the LDS byte offsets of S_j, F_i and of the two entries of H it fills ----
   std::vector<uint32_t> hplan;
   {

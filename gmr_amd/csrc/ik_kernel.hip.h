@@ -105,11 +105,13 @@ struct DevModel {
   // H assembly plan, one entry per structurally non-zero off-diagonal pair (dof j strictly above dof i), padded to a multiple
   // of 64 with entries that land in the dummy slots: LDS byte offsets {S_j | F_i << 16, H[i][j] | H[j][i] << 16}
   uint2 hplan[kMaxPairsPadded];
-  uint4 comp_plan[2 * kMaxCompPass * 64];             // per pass and lane: LDS byte offsets {s0|s1<<16, s2|s3<<16, dst, -}
+  // composite plan per table, pass and half-wave: LDS byte offsets of four source blocks and the destination block
+  // {s0|s1<<16, s2|s3<<16, dst, -}; absent sources point at the zero block, an idle half at a scratch block
+  uint4 comp_plan[2 * kMaxCompPass * 2];
 };
 
 struct LdsLayout {
-  int zero, q, tp, tq, S, F, Lb, V, bodyc, xpos, xquat, B, Bc, H, total_doubles;  // H aliases [xpos, xquat, B, Bc] (dead during the QP)
+  int zero, hplan, cplan, q, tp, tq, S, F, Lb, V, bodyc, xpos, xquat, B, Bc, H, total_doubles;  // H aliases [xpos, xquat, B, Bc] (dead during the QP)
 };
 
 struct IkLaunch {
@@ -856,7 +858,17 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
   double *Bt = lds + lay.B, *Bc = lds + lay.Bc, *S = lds + lay.S, *F = lds + lay.F, *Hm = lds + lay.H;
   double *bodyc = lay.bodyc >= 0 ? lds + lay.bodyc : nullptr;
   if (bodyc) stage_tree(m, lane, bodyc);
-  if (lane == 0) lds[lay.zero] = 0.0;  // the composite plan's "absent block" (never aliased); lds[lay.zero + 1] absorbs idle lanes' writes
+  // Once per wavefront: the zero block (absent sources of the composite plan) and the two phase plans, from the L2-resident
+  // model into LDS, where a plan entry costs one short-latency read per pass instead of an L2 round trip.
+  if (lane < kBT + 1) lds[lay.zero + lane] = 0.0;
+  {
+    uint2 *hp = reinterpret_cast<uint2 *>(lds + lay.hplan);
+    for (int i = lane; i < m.npairp; i += 64) hp[i] = m.hplan[i];
+    uint4 *cp = reinterpret_cast<uint4 *>(lds + lay.cplan);
+    const int n0 = 2 * m.ncpass[0], n1 = 2 * m.ncpass[1];
+    if (lane < n0) cp[lane] = m.comp_plan[lane];
+    if (lane < n1) cp[n0 + lane] = m.comp_plan[2 * kMaxCompPass + lane];
+  }
   const gmr_work_item w = L.items[blockIdx.x];
   const gmr_ik_params prm = L.prm;
 #ifdef GMR_IK_STAMPS
@@ -996,16 +1008,19 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
                       // blocks (task blocks or finished composites) into one composite, element per lane.  A lane's plan entry is
                       // four source byte offsets (absent ones point at a zero) and a destination; no masks, no selects.  Same
                       // wave, so LDS program order makes a pass see the previous one's writes without a barrier.
-          const uint4 *plan = m.comp_plan + tab * (kMaxCompPass * 64) + lane;
           const int np = m.ncpass[tab];
-          char *lb = reinterpret_cast<char *>(lds);
-          uint4 nxt = plan[0];
-          for (int p = 0; p < np; ++p) {
-            const uint4 cur = nxt;
-            if (p + 1 < np) nxt = plan[launder((p + 1) * 64)];
-            const double v0 = *reinterpret_cast<const double *>(lb + (cur.x & 0xffffu)), v1 = *reinterpret_cast<const double *>(lb + (cur.x >> 16));
-            const double v2 = *reinterpret_cast<const double *>(lb + (cur.y & 0xffffu)), v3 = *reinterpret_cast<const double *>(lb + (cur.y >> 16));
-            *reinterpret_cast<double *>(lb + cur.z) = (v0 + v1) + (v2 + v3);
+          if ((lane & 31) < kBT) {  // element of the block; lanes 27..31 of each half idle
+            char *lb = reinterpret_cast<char *>(lds);
+            const unsigned el8 = 8u * (lane & 31);
+            const uint4 *plan = reinterpret_cast<const uint4 *>(lds + lay.cplan) + (tab ? 2 * m.ncpass[0] : 0) + (lane >> 5);
+            uint4 nxt = plan[0];
+            for (int p = 0; p < np; ++p) {
+              const uint4 cur = nxt;
+              if (p + 1 < np) nxt = plan[2 * (p + 1)];
+              const double v0 = *reinterpret_cast<const double *>(lb + ((cur.x & 0xffffu) + el8)), v1 = *reinterpret_cast<const double *>(lb + ((cur.x >> 16) + el8));
+              const double v2 = *reinterpret_cast<const double *>(lb + ((cur.y & 0xffffu) + el8)), v3 = *reinterpret_cast<const double *>(lb + ((cur.y >> 16) + el8));
+              *reinterpret_cast<double *>(lb + (cur.z + el8)) = (v0 + v1) + (v2 + v3);
+            }
           }
         }
         __syncthreads();
@@ -1032,10 +1047,11 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         // host-made plan of LDS byte offsets (padding entries land in the dummy slots)
         auto h_pairs = [&]() {
           char *lb = reinterpret_cast<char *>(lds);
+          const uint2 *hp = reinterpret_cast<const uint2 *>(lds + lay.hplan) + lane;
           uint2 pl[kPairRounds];
 #pragma unroll
           for (int r = 0; r < kPairRounds; r++)
-            if (64 * r < npairp) pl[r] = m.hplan[launder(lane + 64 * r)];  // wave-uniform guard
+            if (64 * r < npairp) pl[r] = hp[64 * r];  // wave-uniform guard
 #pragma unroll
           for (int r = 0; r < kPairRounds; r++) {
             if (64 * r < npairp) {
