@@ -302,13 +302,14 @@ __device__ __forceinline__ void stage_tree(const DevModel &m, int lane, double *
 }
 // bodyc != nullptr: joint tree staged in LDS (default).  nullptr: re-read from the L2-resident model each call -- the
 // variant for builds that trade LDS for occupancy (GMR_IK_STAGE_TREE=0).
+template <bool STAGED>
 __device__ __forceinline__ void fk_phase(const DevModel &m, const double *bodyc, int nbody, int nrounds, int lane, const double *q,
                                          double *xpos, double *xquat) {
   const bool has = lane < nbody;
   int jtype, qadr;
   u64 ancs;
   double pos[3], bq[4], ax[3];
-  if (bodyc) {
+  if constexpr (STAGED) {
     const double *bcst = bodyc + kBodyC * (has ? lane : 0);
     const u64 packed = (u64)__double_as_longlong(bcst[10]);
     jtype = (int)((packed >> 48) & 0xff); qadr = (int)(packed >> 56);
@@ -856,8 +857,8 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
   const int lane = threadIdx.x;
   double *q = lds + lay.q, *xpos = lds + lay.xpos, *xquat = lds + lay.xquat, *tp = lds + lay.tp, *tq = lds + lay.tq;
   double *Bt = lds + lay.B, *Bc = lds + lay.Bc, *S = lds + lay.S, *F = lds + lay.F, *Hm = lds + lay.H;
-  double *bodyc = lay.bodyc >= 0 ? lds + lay.bodyc : nullptr;
-  if (bodyc) stage_tree(m, lane, bodyc);
+  double *bodyc = lds + (GMR_IK_STAGE_TREE ? lay.bodyc : 0);
+  if constexpr (GMR_IK_STAGE_TREE != 0) stage_tree(m, lane, bodyc);
   // Once per wavefront: the zero block (absent sources of the composite plan) and the two phase plans, from the L2-resident
   // model into LDS, where a plan entry costs one short-latency read per pass instead of an L2 round trip.
   if (lane < kBT + 1) lds[lay.zero + lane] = 0.0;
@@ -895,6 +896,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
   __syncthreads();
 
   const int nfr = w.n_burn + w.n_out;
+  bool poses_valid = false;
   for (int kf = 0; kf < nfr; ++kf) {
     const int64_t f = w.frame_begin + kf;
     if (kf == w.n_burn && w.burn_row >= 0 && L.qfinal)  // state the first output frame starts from
@@ -969,7 +971,10 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
       const int ncomp = m.ncomp[tab];
 
       double e[6] = {0, 0, 0, 0, 0, 0}, sh = 0.0, ch = 1.0;
-      fk_phase(m, bodyc, nbody, fkrounds, lane, q, xpos, xquat);
+      // q has not moved since the FK that closed the previous solve (previous stage or previous frame): the poses in LDS
+      // are still those of q, so only the very first stage of a work item evaluates FK at entry.
+      if (!poses_valid) fk_phase<GMR_IK_STAGE_TREE != 0>(m, bodyc, nbody, fkrounds, lane, q, xpos, xquat);
+      poses_valid = true;
       GMR_STAMP(1);
       double curr = fast_sqrt(wave_sum(is_task ? task_residual(t_body, t_slot, xpos, xquat, tp, tq, e, sh, ch) : 0.0));
       GMR_STAMP(2);
@@ -1138,7 +1143,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         __syncthreads();
         GMR_STAMP(9);
         ++solves;
-        GMR_DUP(1) fk_phase(m, bodyc, nbody, fkrounds, lane, q, xpos, xquat);
+        GMR_DUP(1) fk_phase<GMR_IK_STAGE_TREE != 0>(m, bodyc, nbody, fkrounds, lane, q, xpos, xquat);
         GMR_STAMP(1);
         double next = 0.0;
         GMR_DUP(2) next = fast_sqrt(wave_sum(is_task ? task_residual(t_body, t_slot, xpos, xquat, tp, tq, e, sh, ch) : 0.0));
@@ -1186,7 +1191,7 @@ __global__ void __launch_bounds__(64) eval_kernel(const DevModel *__restrict__ m
   const int nq = m.nq, nbody = m.nbody, nslot = m.nslot, root_slot = m.root_slot;
   for (int i = lane; i < nq; i += 64) q[i] = L.qpos[(size_t)f * nq + i];
   __syncthreads();
-  fk_phase(m, nullptr, nbody, m.fkrounds, lane, q, xpos, xquat);
+  fk_phase<false>(m, nullptr, nbody, m.fkrounds, lane, q, xpos, xquat);
   if (L.xpos_out)
     for (int i = lane; i < 3 * nbody; i += 64) L.xpos_out[(size_t)f * 3 * nbody + i] = xpos[i];
   if (L.xquat_out)
