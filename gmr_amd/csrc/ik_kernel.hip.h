@@ -153,23 +153,38 @@ __device__ __forceinline__ double dpp_hop(double v, double ident) {
   return __hiloint2double(hi, lo);
 }
 // Wave reductions in the VALU (6 DPP hops, no LDS round trips); result broadcast from lane 63.
-#define GMR_WAVE_REDUCE(NAME, IDENT, OP)                                 \
-  __device__ __forceinline__ double NAME(double v) {                     \
-    const double id = (IDENT);                                           \
-    v = OP(v, dpp_hop<0x111, 0xf>(v, id)); /* row_shr:1 */               \
-    v = OP(v, dpp_hop<0x112, 0xf>(v, id)); /* row_shr:2 */               \
-    v = OP(v, dpp_hop<0x114, 0xf>(v, id)); /* row_shr:4 */               \
-    v = OP(v, dpp_hop<0x118, 0xf>(v, id)); /* row_shr:8 */               \
-    v = OP(v, dpp_hop<0x142, 0xa>(v, id)); /* row_bcast:15 -> rows 1,3 */ \
-    v = OP(v, dpp_hop<0x143, 0xc>(v, id)); /* row_bcast:31 -> rows 2,3 */ \
-    return rdlane(v, 63);                                                \
+// Lanes without a source keep `old`: the value itself for min / max (idempotent), so no identity has to be materialised.
+#define GMR_WAVE_REDUCE(NAME, OP)                                       \
+  __device__ __forceinline__ double NAME(double v) {                    \
+    v = OP(v, dpp_hop<0x111, 0xf>(v, v)); /* row_shr:1 */               \
+    v = OP(v, dpp_hop<0x112, 0xf>(v, v)); /* row_shr:2 */               \
+    v = OP(v, dpp_hop<0x114, 0xf>(v, v)); /* row_shr:4 */               \
+    v = OP(v, dpp_hop<0x118, 0xf>(v, v)); /* row_shr:8 */               \
+    v = OP(v, dpp_hop<0x142, 0xa>(v, v)); /* row_bcast:15 -> rows 1,3 */ \
+    v = OP(v, dpp_hop<0x143, 0xc>(v, v)); /* row_bcast:31 -> rows 2,3 */ \
+    return rdlane(v, 63);                                               \
   }
-__device__ __forceinline__ double op_add(double a, double b) { return a + b; }
 __device__ __forceinline__ double op_min(double a, double b) { return fmin(a, b); }
 __device__ __forceinline__ double op_max(double a, double b) { return fmax(a, b); }
-GMR_WAVE_REDUCE(wave_sum, 0.0, op_add)
-GMR_WAVE_REDUCE(wave_min, INFINITY, op_min)
-GMR_WAVE_REDUCE(wave_max, -INFINITY, op_max)
+GMR_WAVE_REDUCE(wave_min, op_min)
+GMR_WAVE_REDUCE(wave_max, op_max)
+// Sum: bound_ctrl makes a missing source read as 0 and every row is written, so there is no `old` operand at all.  Rows that
+// receive an extra partial sum (row 2) are never read: only lane 63 is.
+template <int CTRL>
+__device__ __forceinline__ double dpp_hop0(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_hop0<0x111>(v);  // row_shr:1
+  v += dpp_hop0<0x112>(v);  // row_shr:2
+  v += dpp_hop0<0x114>(v);  // row_shr:4
+  v += dpp_hop0<0x118>(v);  // row_shr:8: lane 15 of each row holds the row sum
+  v += dpp_hop0<0x142>(v);  // row_bcast:15: row r += sum of row r-1
+  v += dpp_hop0<0x143>(v);  // row_bcast:31: rows 2,3 += lane 31 = rows 0+1  -> lane 63 = total
+  return rdlane(v, 63);
+}
 
 // ------------------------------------------------------------------ lean float64 math (<= ~1 ulp, no slow paths)
 __device__ __forceinline__ double fast_rsqrt(double x) {
