@@ -1,0 +1,145 @@
+"""BASELINE.json configs 3-5 at their full sizes, checked through size-independent properties.
+
+The oracle needs seconds per few thousand frames, so at these sizes the GPU result is pinned by
+  * a bounded oracle sample (first frames of a few clips): exact parity as in test_gpu_parity;
+  * determinism (two launches are bitwise equal);
+  * clip independence (a clip solved alone == its rows in the batch, bitwise: no state leaks between wavefronts);
+  * the box constraint as an invariant of the path: every hinge stays inside its range (mink ConfigurationLimit, gain 0.95,
+    can approach a bound but never cross it);
+  * solve counts inside [2, 22] (two stages of 1 + at most 10 solves) and no QP iteration cap hit;
+  * exactly reachable inputs are tracked: the stage errors at the solved configuration stay small.
+Inputs are synthetic in the shape the configs name (no AMASS / LAFAN1 data exists offline).
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from gmr_amd import synth  # noqa: E402
+from gmr_amd.schedule import make_items  # noqa: E402
+from oracle.oracle import Oracle  # noqa: E402
+from tests.util import compiled  # noqa: E402
+
+
+def _engine(cm):
+    from gmr_amd.engine import Engine
+    return Engine(cm, 0)
+
+
+def _hinge_limits(cm):
+    r = cm.robot
+    hb = sorted(r.hinge_bodies(), key=lambda b: r.qpos_adr[b])  # hinge order of qpos[7:]
+    lim = np.array(r.jnt_range, dtype=np.float64)[hb]
+    return lim[:, 0], lim[:, 1]
+
+
+def _check_invariants(cm, q, iters, n_frames):
+    it = (iters & 0x3FFFFFFF)
+    assert int((iters >> 30).sum().item()) == 0, "a QP hit its iteration cap"
+    assert int(it.min().item()) >= 2 and int(it.max().item()) <= 22
+    assert q.shape == (n_frames, cm.robot.nq) and bool(torch.isfinite(q).all().item())
+    lo, hi = _hinge_limits(cm)
+    lo_t, hi_t = torch.from_numpy(lo).to(q.device), torch.from_numpy(hi).to(q.device)
+    hinges = q[:, 7:]
+    assert float((lo_t - hinges).max().item()) <= 1e-9 and float((hinges - hi_t).max().item()) <= 1e-9
+    assert float((q[:, 3:7].norm(dim=1) - 1.0).abs().max().item()) < 1e-12
+
+
+def _tile_variable(pos, quat, base_T, lengths, rng):
+    """Clips of the given lengths cut from randomly chosen base clips (each a prefix, so frame 0 is a valid start)."""
+    nb = pos.shape[0] // base_T
+    idx = []
+    for L in lengths:
+        b = int(rng.integers(nb))
+        idx.append(np.arange(b * base_T, b * base_T + L))
+    idx = np.concatenate(idx)
+    offs = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    return idx, offs
+
+
+def test_config3_lafan_sized_bvh_set():
+    """LAFAN1-shaped: 77 clips of 2000..9000 frames through bvh_to_g1.json (scripts/bvh_to_robot_dataset.py path)."""
+    cm = compiled("bvh", "unitree_g1")
+    eng = _engine(cm)
+    rng = np.random.default_rng(3)
+    base_T, n_base = 9000, 8
+    pos, quat, names, _, _ = synth.synth_clips(cm, n_base, base_T, seed=33, hard=False, dtype=np.float32)
+    hpos, hquat, _, _, _ = synth.synth_clips(cm, n_base, base_T, seed=34, hard=True, dtype=np.float32)
+    pos, quat = np.concatenate([pos, hpos]), np.concatenate([quat, hquat])  # bases 0..7 reachable, 8..15 noisy / over-reach
+    lengths = rng.integers(2000, 9001, size=77)
+    idx, offs = _tile_variable(pos, quat, base_T, lengths, rng)
+    N = int(offs[-1])
+    assert 3.0e5 < N < 6.0e5
+    dev = eng.device
+    tp, tq = torch.from_numpy(pos).to(dev)[torch.from_numpy(idx).to(dev)], torch.from_numpy(quat).to(dev)[torch.from_numpy(idx).to(dev)]
+    sc = cm.slot_columns(names)
+    q, it, _ = eng.ik_solve(tp, tq, sc, make_items(offs))
+    _check_invariants(cm, q, it, N)
+    q2, it2, _ = eng.ik_solve(tp, tq, sc, make_items(offs))
+    assert torch.equal(q, q2) and torch.equal(it, it2)  # deterministic
+    for c in (0, 38, 76):  # clip independence, bitwise
+        a, b = int(offs[c]), int(offs[c + 1])
+        qc, _, _ = eng.ik_solve(tp[a:b].contiguous(), tq[a:b].contiguous(), sc, make_items([0, b - a]))
+        assert torch.equal(qc, q[a:b])
+    orc = Oracle(cm.blob)
+    for c in (1, 40):  # bounded oracle sample
+        a = int(offs[c])
+        q_ref, it_ref, _ = orc.ik_solve(tp[a:a + 150].cpu().numpy(), tq[a:a + 150].cpu().numpy(), sc, make_items([0, 150]))
+        assert np.abs(q[a:a + 150].cpu().numpy() - q_ref).max() < 1e-6
+        assert np.array_equal((it[a:a + 150] & 0x3FFFFFFF).cpu().numpy(), it_ref)
+
+
+def test_config4_five_robots_concurrently_full_size():
+    """5 robots x 64 clips x 1000 frames, one model handle and one HIP stream per robot, all in flight together."""
+    robots = ["unitree_g1", "booster_t1", "stanford_toddy", "fourier_n1", "engineai_pm01"]
+    jobs = []
+    for r in robots:
+        cm = compiled("smplx", r)
+        eng = _engine(cm)
+        pos, quat, names, offs8, _ = synth.synth_clips(cm, 8, 1000, seed=41, hard=False, dtype=np.float32)
+        rep = lambda a: torch.from_numpy(a).to(eng.device).repeat(8, 1, 1)  # 64 clips from 8 distinct
+        offs = np.arange(65, dtype=np.int64) * 1000
+        jobs.append((cm, eng, rep(pos), rep(quat), names, offs, torch.cuda.Stream(eng.device)))
+    torch.cuda.synchronize()
+    outs = []
+    for cm, eng, tp, tq, names, offs, st in jobs:
+        with torch.cuda.stream(st):
+            outs.append(eng.ik_solve(tp, tq, cm.slot_columns(names), make_items(offs)))
+    torch.cuda.synchronize()
+    for (cm, eng, tp, tq, names, offs, _), (q, it, _) in zip(jobs, outs):
+        _check_invariants(cm, q, it, 64000)
+        assert torch.equal(q[:8000], q[8000:16000]) and torch.equal(q[:8000], q[56000:])  # identical clips, identical rows
+        # exactly reachable inputs are tracked: stage errors at the solved configuration (settled part of each clip)
+        e, _, _ = eng.evaluate(q[:8000], tp[:8000], tq[:8000], cm.slot_columns(names))
+        settled = torch.cat([e[c * 1000 + 30:(c + 1) * 1000] for c in range(8)])
+        assert float(settled.max().item()) < 5e-2, float(settled.max().item())
+        q_ref, it_ref, _ = Oracle(cm.blob).ik_solve(tp[:120].cpu().numpy(), tq[:120].cpu().numpy(), cm.slot_columns(names), make_items([0, 120]))
+        assert np.abs(q[:120].cpu().numpy() - q_ref).max() < 1e-6
+
+
+def test_config5_hands_model_full_size():
+    """unitree_g1_with_hands (43 hinges, deepest tree) over 2048 clips x 3000 frames = 6.1 M frames in one launch."""
+    cm = compiled("smplx", "unitree_g1_with_hands")
+    eng = _engine(cm)
+    S, T, D = 2048, 3000, 16
+    pos, quat, names, _, _ = synth.synth_clips(cm, D // 2, T, seed=51, hard=False, dtype=np.float32)
+    hpos, hquat, _, _, _ = synth.synth_clips(cm, D // 2, T, seed=52, hard=True, dtype=np.float32)
+    dev = eng.device
+    tp = torch.from_numpy(np.concatenate([pos, hpos])).to(dev).repeat(S // D, 1, 1)
+    tq = torch.from_numpy(np.concatenate([quat, hquat])).to(dev).repeat(S // D, 1, 1)
+    offs = np.arange(S + 1, dtype=np.int64) * T
+    sc = cm.slot_columns(names)
+    q, it, _ = eng.ik_solve(tp, tq, sc, make_items(offs))
+    torch.cuda.synchronize()
+    _check_invariants(cm, q, it, S * T)
+    # the 14 hand hinges have no task below them: exactly zero, always (reference quirk 8)
+    g1 = compiled("smplx", "unitree_g1")  # only for its body names (the two MJCFs differ in link geometry, so motions do too)
+    hb = sorted(cm.robot.hinge_bodies(), key=lambda b: cm.robot.qpos_adr[b])
+    hand = [i for i, b in enumerate(hb) if cm.robot.body_names[b] not in set(g1.robot.body_names)]
+    assert len(hand) == 14 and float(q[:, 7:][:, hand].abs().max().item()) == 0.0
+    # tiling: every repetition of the 16 distinct clips gives the same rows
+    block = D * T
+    assert torch.equal(q[:block], q[block:2 * block]) and torch.equal(q[:block], q[(S // D - 1) * block:])
+    q_ref, it_ref, _ = Oracle(cm.blob).ik_solve(tp[8 * T:8 * T + 150].cpu().numpy(), tq[8 * T:8 * T + 150].cpu().numpy(), sc, make_items([0, 150]))
+    assert np.abs(q[8 * T:8 * T + 150].cpu().numpy() - q_ref).max() < 1e-6
