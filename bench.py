@@ -132,7 +132,7 @@ def main():
 
     def barrier():
         if world > 1:
-            torch.distributed.barrier()
+            torch.distributed.barrier(device_ids=[local])  # RCCL: the barrier runs on this rank's own GPU
 
     for _ in range(args.warmup):
         step()
