@@ -904,6 +904,14 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
   const int sq_g = SQ ? (int)m.sq_gdof[lane] : -1;
   const bool sq_own = SQ ? m.sq_owner[lane] != 0 : false, sq_pad = sq_g < 0;
   const int sq_mydiag = SQ && real_row ? m.sq_diag[lane] : 0;
+  // joint range and qpos address of the dof this lane owns in the structured QP layout, kept in registers: the limits are
+  // rebuilt every solve and must not wait for L2.  Unlimited dofs get an infinite range.
+  int sq_qadr = 0;
+  double sq_rlo = -INFINITY, sq_rhi = INFINITY;
+  if (SQ && sq_own) {
+    sq_qadr = m.aqadr[sq_g];
+    if (m.alimited[sq_g]) { sq_rlo = m.arange[2 * sq_g]; sq_rhi = m.arange[2 * sq_g + 1]; }
+  }
   double *V = lds + lay.V;
   int sq_status = 0;
   for (int i = lane; i < nq; i += 64) q[i] = w.init_row >= 0 ? L.qinit[(size_t)w.init_row * nq + i] : m.qpos0[i];
@@ -1010,7 +1018,13 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
             const double qb[4] = {xquat[4 * a_body], xquat[4 * a_body + 1], xquat[4 * a_body + 2], xquat[4 * a_body + 3]};
             const double xb[3] = {xpos[3 * a_body], xpos[3 * a_body + 1], xpos[3 * a_body + 2]};
             const int ab = launder(a_body);
-            const double a_axis[3] = {m.axis[3 * ab], m.axis[3 * ab + 1], m.axis[3 * ab + 2]};
+            double a_axis[3];
+            if constexpr (GMR_IK_STAGE_TREE != 0) {  // the staged joint tree carries the axis: no L2 read inside the solve
+              const double *bc = bodyc + kBodyC * a_body + 7;
+              a_axis[0] = bc[0]; a_axis[1] = bc[1]; a_axis[2] = bc[2];
+            } else {
+              a_axis[0] = m.axis[3 * ab]; a_axis[1] = m.axis[3 * ab + 1]; a_axis[2] = m.axis[3 * ab + 2];
+            }
             double R[9], ax[3], mo[3];
             q2mat(qb, R);
             if (a_kind < 6) { ax[0] = R[a_kind - 3]; ax[1] = R[a_kind]; ax[2] = R[a_kind + 3]; }  // root-body-frame axes
@@ -1100,12 +1114,9 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
           GMR_STAMP(7);
           const int gi = launder(sq_own ? sq_g : 0);
           const double s_ci = sq_own ? V[gi] : 0.0;
-          double s_lo = -1e30, s_hi = 1e30;
-          if (sq_own && m.alimited[gi]) {  // mink ConfigurationLimit, evaluated by the lane that owns the dof in the QP layout
-            const double qv = q[m.aqadr[gi]];
-            s_lo = -prm.limit_gain * (qv - m.arange[2 * gi]);
-            s_hi = prm.limit_gain * (m.arange[2 * gi + 1] - qv);
-          }
+          // mink ConfigurationLimit, evaluated by the lane that owns the dof in the QP layout: -gain (q - lower) <= dq <= gain (upper - q)
+          const double qv = q[sq_qadr];
+          const double s_lo = fmax(-prm.limit_gain * (qv - sq_rlo), -1e30), s_hi = fmin(prm.limit_gain * (sq_rhi - qv), 1e30);
           double xs;
 #ifdef GMR_DUP_PHASE
           if (GMR_DUP_PHASE == 8) { int st2 = sq_status; double x2; (void)box_qp_struct(lane, m.sq_nlimb, sq_own, sq_pad, Hm, lds + lay.Lb, s_ci, s_lo, s_hi, st2, x2); asm volatile("" :: "v"(x2)); }
