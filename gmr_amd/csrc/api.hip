@@ -35,7 +35,7 @@ struct gmr_model {
   const gmr::DevModel *dm_dev = nullptr;  // the struct in device memory: the one model argument of the IK kernels
   gmr::FkTree fk{};
   gmr::LdsLayout lay{};
-  int nvp = 0, n_act = 0, lds_bytes = 0, fk_lds_bytes = 0;
+  int nvp = 0, n_act = 0, lds_bytes = 0, fk_lds_bytes = 0, fk_lds_bytes_min = 0;  // _min: the min-height mode has no output stage
   // grow-only workspace for per-call scheduling data
   void *ws = nullptr;
   size_t ws_bytes = 0;
@@ -594,7 +594,9 @@ int build_device_model(gmr_model *m) {
 #undef DP
   memcpy(P.buf.data() + o_dm, &dm, sizeof(dm));
   HIP_TRY(m, hipMemcpy(m->dev, P.buf.data(), P.buf.size(), hipMemcpyHostToDevice));
-  m->fk_lds_bytes = std::max(1, nslots) * 7 * gmr::kFkThreads * (int)sizeof(float);
+  // branch slots + dof tile + position / rotation stages (fk_kernel.hip.h)
+  m->fk_lds_bytes = (std::max(1, nslots) * 7 + std::max(1, nq - 7) + gmr::kFkPosStride + gmr::kFkRotStride) * gmr::kFkThreads * (int)sizeof(float);
+  m->fk_lds_bytes_min = (std::max(1, nslots) * 7 + std::max(1, nq - 7)) * gmr::kFkThreads * (int)sizeof(float);
 
   if (m->lds_bytes > 160 * 1024) { set_err(m, "model needs %d bytes of LDS per wavefront", m->lds_bytes); return GMR_EUNSUPPORTED; }
   // opt in to > 64 KiB of dynamic LDS where a variant needs it
@@ -898,7 +900,7 @@ int gmr_fk_min_height(gmr_model *m, const float *root_pos, const float *root_rot
   if (n_frames > 0) {
     const int64_t nblk = (n_frames + gmr::kFkThreads - 1) / gmr::kFkThreads;
     if (nblk > 0x7fffffff) { set_err(m, "too many frames for one launch"); return GMR_EINVAL; }
-    hipLaunchKernelGGL((gmr::fk_kernel<1>), dim3((unsigned)nblk), dim3(gmr::kFkThreads), m->fk_lds_bytes, st, m->fk, root_pos, root_rot_xyzw, dof,
+    hipLaunchKernelGGL((gmr::fk_kernel<1>), dim3((unsigned)nblk), dim3(gmr::kFkThreads), m->fk_lds_bytes_min, st, m->fk, root_pos, root_rot_xyzw, dof,
                        n_frames, (float *)nullptr, (float *)nullptr, static_cast<const int64_t *>(m->ws), n_seq, keys);
   }
   hipLaunchKernelGGL(gmr::fk_minkey_decode, dim3((n_seq + 255) / 256), dim3(256), 0, st, keys, min_z_out, n_seq);

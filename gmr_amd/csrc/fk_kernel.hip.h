@@ -5,9 +5,14 @@
 // dataset scripts after IK (scripts/smplx_to_robot_dataset.py:106-123, bvh_to_robot_dataset.py:108-125).
 //
 // One frame per lane.  The joint tree is wave-uniform, so its constants come in through scalar loads
-// (SGPRs) and a copy staged in LDS once per workgroup; the chain itself runs in VGPRs.  Bodies are in
-// depth-first order, so a body's parent is either the previous body (pose still in registers) or an
-// earlier branch point whose pose was parked in a per-lane LDS slot (slot lifetimes planned on the host).
+// (SGPRs); the chain itself runs in VGPRs.  Bodies are in depth-first order, so a body's parent is either
+// the previous body (pose still in registers) or an earlier branch point whose pose was parked in a
+// per-lane LDS slot (slot lifetimes planned on the host).
+// HBM access is tile-wise, not per lane: a workgroup's frames are contiguous rows of every array, so the
+// dof rows come in as one coalesced copy into LDS, and the poses go out through an LDS stage, kFkGroup
+// bodies at a time, as runs of kFkGroup x 12 (16) contiguous bytes per frame written by consecutive lanes.
+// (With one lane storing its own frame directly, every store instruction touched 64 different cache lines
+// and the kernel sat at the L2 request rate, 9 % of the HBM roofline.)
 // Algorithmic HBM traffic per frame: (3+4+ndof) x 4 B in, nbody x 12 B out (+ nbody x 16 B if rotations
 // are requested).
 #pragma once
@@ -15,9 +20,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace gmr {
 
-constexpr int kFkThreads = 256;
+constexpr int kFkThreads = 128;
+constexpr int kFkGroup = 4;                        // bodies per output flush
+constexpr int kFkPosStride = 3 * kFkGroup + 1;    // LDS words per lane of the position stage (odd: conflict-free)
+constexpr int kFkRotStride = 4 * kFkGroup + 1;
 constexpr int kFkMaxSlots = 12;
 
 struct FkTree {     // device arrays, [nbody]
@@ -52,6 +62,8 @@ __device__ __forceinline__ void fk_quat_rotate(const float q[4], const float v[3
 }
 
 // MODE 0: write body_pos (and body_rot if non-null).  MODE 1: per-clip min of z (atomics on an ordered-int key).
+// Dynamic LDS (floats): [nslots][7][kFkThreads] branch slots | [kFkThreads][ndof] dof tile |
+//                       [kFkThreads][kFkPosStride] position stage | [kFkThreads][kFkRotStride] rotation stage (MODE 0)
 template <int MODE>
 __global__ void __launch_bounds__(kFkThreads) fk_kernel(FkTree t, const float *__restrict__ root_pos,
                                                         const float *__restrict__ root_rot, const float *__restrict__ dof,
@@ -59,34 +71,73 @@ __global__ void __launch_bounds__(kFkThreads) fk_kernel(FkTree t, const float *_
                                                         float *__restrict__ body_rot, const int64_t *__restrict__ seq_offsets,
                                                         int n_seq, int *__restrict__ min_key) {
 #pragma clang fp contract(off)  // torch does not fuse; also keeps MODE 0 and MODE 1 bit-identical
-  extern __shared__ float fk_lds[];  // [nslots][7][kFkThreads]
+  extern __shared__ float fk_lds[];
   const int tid = threadIdx.x;
-  const int64_t f = (int64_t)blockIdx.x * kFkThreads + tid;
-  const bool live = f < n_frames;
+  const int nbody = t.nbody, ndof = t.ndof;
+  const int64_t f0 = (int64_t)blockIdx.x * kFkThreads;
+  const int64_t f = f0 + tid;
+  const int nfb = (int)(n_frames - f0 < kFkThreads ? n_frames - f0 : kFkThreads);  // frames of this workgroup
+  const bool live = tid < nfb;
   const int64_t fc = live ? f : n_frames - 1;  // clamp: dead lanes recompute the last frame, never store
+  float *slots = fk_lds;
+  float *dtile = slots + (size_t)t.nslots * 7 * kFkThreads;
+  float *pstage = dtile + (size_t)kFkThreads * ndof;
+  float *rstage = pstage + kFkThreads * kFkPosStride;
+  // dof tile: rows f0 .. f0+nfb-1 are contiguous in memory -> one coalesced copy
+  {
+    const float *src = dof + f0 * ndof;
+    const int n = nfb * ndof;
+    for (int i = tid; i < n; i += kFkThreads) dtile[i] = src[i];
+  }
   float cp[3], cr[4];
 #pragma unroll
   for (int i = 0; i < 3; i++) cp[i] = root_pos[fc * 3 + i];
 #pragma unroll
   for (int i = 0; i < 4; i++) cr[i] = root_rot[fc * 4 + i];
   float zmin = cp[2];
-  if (MODE == 0 && live) {
-#pragma unroll
-    for (int i = 0; i < 3; i++) body_pos[(fc * t.nbody) * 3 + i] = cp[i];
-    if (body_rot) {
-#pragma unroll
-      for (int i = 0; i < 4; i++) body_rot[(fc * t.nbody) * 4 + i] = cr[i];
-    }
-  }
   if (t.save_slot[0] >= 0) {
-    float *s = fk_lds + (size_t)t.save_slot[0] * 7 * kFkThreads + tid;
+    float *s = slots + (size_t)t.save_slot[0] * 7 * kFkThreads + tid;
 #pragma unroll
     for (int i = 0; i < 3; i++) s[i * kFkThreads] = cp[i];
 #pragma unroll
     for (int i = 0; i < 4; i++) s[(3 + i) * kFkThreads] = cr[i];
   }
-  const float *mydof = dof + fc * t.ndof;
-  for (int j = 1; j < t.nbody; ++j) {
+  __syncthreads();  // dof tile complete
+  const float *mydof = dtile + (live ? tid : nfb - 1) * ndof;
+  const bool want_rot = MODE == 0 && body_rot != nullptr;
+  // flush the stage: bodies j0 .. j0+cnt-1 of every frame of the workgroup, consecutive lanes -> consecutive words
+  struct F3 { float x, y, z; };  // 12 bytes, 4-byte aligned: one global_store_dwordx3 per body
+  auto flush_n = [&](int j0, const auto cnt) {  // cnt: int, or an integral constant so that the index split is a shift
+    __syncthreads();
+    {
+      const int n = nfb * cnt;  // one (frame, body) item per lane and store
+      for (int i = tid; i < n; i += kFkThreads) {
+        const int fr = i / cnt, b = i - fr * cnt;
+        const float *sp = pstage + fr * kFkPosStride + 3 * b;
+        *reinterpret_cast<F3 *>(body_pos + ((f0 + fr) * nbody + j0 + b) * 3) = F3{sp[0], sp[1], sp[2]};
+      }
+    }
+    if (want_rot) {
+      const int n = nfb * cnt;
+      for (int i = tid; i < n; i += kFkThreads) {
+        const int fr = i / cnt, b = i - fr * cnt;
+        const float *sp = rstage + fr * kFkRotStride + 4 * b;
+        *reinterpret_cast<float4 *>(body_rot + ((f0 + fr) * nbody + j0 + b) * 4) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+      }
+    }
+    __syncthreads();
+  };
+  auto stage = [&](int k) {  // pose of the current body into stage column k
+#pragma unroll
+    for (int i = 0; i < 3; i++) pstage[tid * kFkPosStride + 3 * k + i] = cp[i];
+    if (want_rot) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) rstage[tid * kFkRotStride + 4 * k + i] = cr[i];
+    }
+  };
+  if (MODE == 0) stage(0);
+  for (int j = 1; j < nbody; ++j) {
+    if (MODE == 0 && (j % kFkGroup) == 0) flush_n(j - kFkGroup, std::integral_constant<int, kFkGroup>{});
     float pp[3], pr[4];
     const int src = t.src_slot[j];
     if (src < 0) {
@@ -95,7 +146,7 @@ __global__ void __launch_bounds__(kFkThreads) fk_kernel(FkTree t, const float *_
 #pragma unroll
       for (int i = 0; i < 4; i++) pr[i] = cr[i];
     } else {
-      const float *s = fk_lds + (size_t)src * 7 * kFkThreads + tid;
+      const float *s = slots + (size_t)src * 7 * kFkThreads + tid;
 #pragma unroll
       for (int i = 0; i < 3; i++) pp[i] = s[i * kFkThreads];
 #pragma unroll
@@ -106,11 +157,18 @@ __global__ void __launch_bounds__(kFkThreads) fk_kernel(FkTree t, const float *_
     if (di >= 0) {
       // axis_angle_to_quat: sin/cos in float32, the product with the float64 axis and the renormalisation in float64
       const float th = mydof[di] / 2.0f;
-      const double s = (double)sinf(th), c = (double)cosf(th);
+      float sf, cf;
+      sincosf(th, &sf, &cf);  // one range reduction for both; same values as sinf / cosf
+      const double s = (double)sf, c = (double)cf;
       const double qx = t.jaxis64[3 * j] * s, qy = t.jaxis64[3 * j + 1] * s, qz = t.jaxis64[3 * j + 2] * s;
-      double n = sqrt(qx * qx + qy * qy + qz * qz + c * c);
-      n = n < 1e-9 ? 1e-9 : n;
-      jq[0] = (float)(qx / n); jq[1] = (float)(qy / n); jq[2] = (float)(qz / n); jq[3] = (float)(c / n);
+      // / max(|q|, 1e-9) in float64: |q| = 1 to float32 rounding here (unit axis, sin^2 + cos^2), so the clamp never binds and
+      // a Newton-refined reciprocal square root (<= 1 ulp in float64, invisible after the cast to float32) replaces sqrt + 4 divides
+      const double n2 = qx * qx + qy * qy + qz * qz + c * c;
+      double r = __builtin_amdgcn_rsq(n2);
+      r = r * (1.5 - 0.5 * n2 * r * r);
+      r = r * (1.5 - 0.5 * n2 * r * r);
+      r = n2 < 1e-18 ? 1e9 : r;
+      jq[0] = (float)(qx * r); jq[1] = (float)(qy * r); jq[2] = (float)(qz * r); jq[3] = (float)(c * r);
     }
     const float lt[3] = {t.lpos[3 * j], t.lpos[3 * j + 1], t.lpos[3 * j + 2]};
     const float lr[4] = {t.lrot[4 * j], t.lrot[4 * j + 1], t.lrot[4 * j + 2], t.lrot[4 * j + 3]};
@@ -120,38 +178,41 @@ __global__ void __launch_bounds__(kFkThreads) fk_kernel(FkTree t, const float *_
     for (int i = 0; i < 3; i++) cp[i] = pp[i] + wt[i];
     fk_quat_mul(lr, jq, tmp);
     fk_quat_mul(pr, tmp, cr);
-    if (MODE == 0) {
-      if (live) {
-#pragma unroll
-        for (int i = 0; i < 3; i++) body_pos[(fc * t.nbody + j) * 3 + i] = cp[i];
-        if (body_rot) {
-#pragma unroll
-          for (int i = 0; i < 4; i++) body_rot[(fc * t.nbody + j) * 4 + i] = cr[i];
-        }
-      }
-    } else {
-      zmin = fminf(zmin, cp[2]);
-    }
+    if (MODE == 0) stage(j % kFkGroup);
+    else zmin = fminf(zmin, cp[2]);
     const int sv = t.save_slot[j];
     if (sv >= 0) {
-      float *s = fk_lds + (size_t)sv * 7 * kFkThreads + tid;
+      float *s = slots + (size_t)sv * 7 * kFkThreads + tid;
 #pragma unroll
       for (int i = 0; i < 3; i++) s[i * kFkThreads] = cp[i];
 #pragma unroll
       for (int i = 0; i < 4; i++) s[(3 + i) * kFkThreads] = cr[i];
     }
   }
-  if (MODE == 1 && live) {
+  if (MODE == 0) {
+    const int j0 = (nbody - 1) / kFkGroup * kFkGroup;  // the last, possibly partial, group
+    flush_n(j0, nbody - j0);
+  }
+  if (MODE == 1) {  // every lane takes part: dead lanes carry a copy of the last frame, which cannot change its clip's minimum
     // clip of this frame: binary search in seq_offsets (wave-divergent, tiny)
     int lo = 0, hi = n_seq;
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
-      if (seq_offsets[mid] <= f) lo = mid; else hi = mid;
+      if (seq_offsets[mid] <= fc) lo = mid; else hi = mid;
     }
     // order-preserving int key of a float: flip the magnitude bits of negatives
     int k = __float_as_int(zmin);
     k = k >= 0 ? k : (k ^ 0x7fffffff);
-    atomicMin(min_key + lo, k);
+    // clips are thousands of frames long: almost every wavefront sits inside one clip, so reduce in the wave and issue one
+    // atomic instead of 64 contending ones; wavefronts that straddle a boundary fall back to one atomic per lane
+    const int lo0 = __builtin_amdgcn_readfirstlane(lo);
+    if (__all(lo == lo0)) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) k = min(k, __shfl_xor(k, off));
+      if ((tid & 63) == 0) atomicMin(min_key + lo0, k);
+    } else {
+      atomicMin(min_key + lo, k);
+    }
   }
 }
 
