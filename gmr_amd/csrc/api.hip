@@ -556,7 +556,7 @@ int build_device_model(gmr_model *m) {
 
   gmr::DevModel &dm = m->dm;
   dm = gmr::DevModel{};
-  dm.nbody = nb; dm.nq = nq; dm.nv = nv; dm.nslot = ns; dm.root_slot = h.root_slot; dm.maxdepth = maxdepth; dm.n_act = n_act;
+  dm.nbody = nb; dm.nq = nq; dm.nv = nv; dm.nslot = ns; dm.root_slot = h.root_slot; dm.n_act = n_act;
   for (int k = 0; k < 2; ++k) { dm.ntask[k] = h.ntask[k]; dm.use_table[k] = h.use_table[k] && h.ntask[k] > 0; dm.ncomp[k] = ncomp[k]; dm.ncpass[k] = ncpass[k]; }
   dm.npairp = (int)hplan.size() / 2; dm.fkrounds = fkrounds; dm.sq_ok = sq_ok; dm.sq_nlimb = sq_nlimb;
   bool fits = true;
@@ -566,12 +566,12 @@ int build_device_model(gmr_model *m) {
     if (src.size() * sizeof(src[0]) > sizeof(dst)) { fits = false; return; }
     if (!src.empty()) memcpy(&dst[0], src.data(), src.size() * sizeof(src[0]));
   };
-  put(dm.parent, v_parent); put(dm.jtype, v_jtype); put(dm.qadr, v_qadr); put(dm.depth, depth);
+  put(dm.jtype, v_jtype); put(dm.qadr, v_qadr);
   put(dm.bpos, v_bpos); put(dm.bquat, v_bquat); put(dm.axis, v_axis); put(dm.qpos0, v_qpos0);
   put(dm.sscale, v_sscale); put(dm.spoff, v_spoff); put(dm.sroff, v_sroff); put(dm.sfoot, v_sfoot);
   put(dm.tbody, tbody); put(dm.tslot, tslot); put(dm.twp, twp); put(dm.twr, twr);
   put(dm.abody, abody); put(dm.akind, akind); put(dm.aqadr, aqadr); put(dm.alimited, alim);
-  put(dm.aanc, aanc); put(dm.arange, arange); put(dm.acomp, acomp); put(dm.compmask, compmask);
+  put(dm.arange, arange); put(dm.acomp, acomp);
   put(dm.hplan, hplan); put(dm.fkanc, fkanc); put(dm.comp_plan, comp_plan);
   put(dm.sq_gdof, sq_gdof); put(dm.sq_owner, sq_owner); put(dm.sq_lane_of_dof, sq_lane_of_dof); put(dm.sq_diag, sq_diag);
   if (!fits) { set_err(m, "internal: a model table exceeds its fixed capacity"); return GMR_EUNSUPPORTED; }

@@ -7,13 +7,16 @@
 // concurrently, one per wavefront; nothing is exchanged between them.
 //
 // Lane roles change per phase (all state that crosses phases lives in LDS):
-//   FK            lane = body        level-synchronous quaternion chain down the joint tree
-//   residual      lane = task        SE3 log of T_body^-1 T_target, |e| by wave reduction
+//   FK            lane = body        pointer jumping up the joint tree: ceil(log2(depth+1)) LDS round trips
+//   residual      lane = task        SE3 log of T_body^-1 T_target, |e| by a DPP wave reduction
 //   task blocks   lane = task        6x6 "task inertia" B_t = A_t' W^2 A_t and g_t = A_t' W^2 e_t
-//   composites    lane = (node,elt)  B^c = sum of B_t below a joint (composite-rigid-body style)
-//   H, c          lane = dof (row)   H[i][j] = S_j . (B^c_i S_i) for j an ancestor of i; row i in VGPRs
-//   box QP        lane = dof (row)   in-register Cholesky, broadcast-style forward/backward solves,
-//                                    primal active set with warm-started working set
+//   composites    lane = (half,elt)  B^c = sum of B_t below a joint (composite-rigid-body style), two composites per pass
+//                                    from a host-made plan of LDS offsets
+//   F, c          lane = dof         F_i = B^c_i S_i, c_i = S_i . g^c_i
+//   H             lane = pair        H[i][j] = S_j . F_i for every structurally non-zero pair, from a host-made plan
+//   box QP        lane = QP row      structured (core + limbs in four 16-lane groups, LDL' with DPP row broadcasts, no LDS)
+//                                    or generic dense (rows in VGPRs, LDS-broadcast Cholesky); primal active set with
+//                                    warm-started working set
 //   integrate     lane = dof
 // All arithmetic is float64: gfx950 issues v_fma_f64 at the same rate as unpacked v_fma_f32, and
 // the reference's `curr_error - next_error > 1e-3` loop test (motion_retarget.py:153,172) is
@@ -60,9 +63,6 @@ typedef unsigned long long u64;
 #ifndef GMR_QP_GROUP
 #define GMR_QP_GROUP 6
 #endif
-#ifndef GMR_SQ_ELIM_DPP
-#define GMR_SQ_ELIM_DPP 1  // structured QP: pivot rows by DPP row_newbcast (1) or through two LDS rows (0)
-#endif
 #ifndef GMR_IK_STAGE_TREE
 #define GMR_IK_STAGE_TREE 1  // joint tree staged in LDS per wavefront; 0 = re-read from L2 (saves 3.3 KB LDS for G1)
 #endif
@@ -79,26 +79,24 @@ constexpr double kLieEps = 1e-10;  // mink.lie.utils.get_epsilon(float64)
 // of two per table (with ~45 tables passed by value the kernel spilled hundreds of SGPRs into VGPR lanes).
 constexpr int kMaxPairsPadded = (GMR_MAX_BODIES * (GMR_MAX_BODIES - 1) / 2 + 63) / 64 * 64;
 struct DevModel {
-  int nbody, nq, nv, nslot, root_slot, maxdepth, n_act, pad0;
+  int nbody, nq, nv, nslot, root_slot, n_act, pad0, pad1;
   int ntask[2], use_table[2], ncomp[2], ncpass[2];  // ncpass: composite passes per table
   int npairp, fkrounds, sq_ok, sq_nlimb;              // npairp: entries of hplan (a multiple of 64)
   // per active dof [64]
   int abody[64], akind[64], aqadr[64], alimited[64];  // akind: 0..2 root translation, 3..5 root rotation, 6 hinge
   double arange[128];                                 // [64][2]
   int acomp[2 * 64];                                  // composite node of the dof per table
-  u64 aanc[64];                                       // active dofs strictly above (lower index)
   // per task, table-major [2][GMR_MAX_TASKS]
   int tbody[2 * GMR_MAX_TASKS], tslot[2 * GMR_MAX_TASKS];
   double twp[2 * GMR_MAX_TASKS], twr[2 * GMR_MAX_TASKS];
   // per body [nbody]
-  int parent[GMR_MAX_BODIES], jtype[GMR_MAX_BODIES], qadr[GMR_MAX_BODIES], depth[GMR_MAX_BODIES];
+  int jtype[GMR_MAX_BODIES], qadr[GMR_MAX_BODIES];
   double bpos[3 * GMR_MAX_BODIES], bquat[4 * GMR_MAX_BODIES], axis[3 * GMR_MAX_BODIES];  // bquat: unit wxyz
   u64 fkanc[GMR_MAX_BODIES];                          // byte r = ancestor folded in FK round r (0xff: none)
   double qpos0[GMR_MAX_BODIES + 8];                   // [nq]
   // per slot [nslot]
   double sscale[GMR_MAX_SLOTS], spoff[3 * GMR_MAX_SLOTS], sroff[4 * GMR_MAX_SLOTS];
   int sfoot[GMR_MAX_SLOTS];
-  unsigned compmask[2 * 2 * GMR_MAX_TASKS];           // tasks summed into each composite
   // structured QP (box_qp_struct): 4 groups of 16 lanes, each = one bin of limb dofs + a copy of the core dofs
   signed char sq_gdof[64], sq_owner[64];              // dof of a structured lane (-1 padding); 1 if the lane owns that dof
   int sq_lane_of_dof[64], sq_diag[64];                // per dof: its owner lane; LDS index of its diagonal entry
@@ -111,7 +109,9 @@ struct DevModel {
 };
 
 struct LdsLayout {
-  int zero, hplan, cplan, q, tp, tq, S, F, Lb, V, bodyc, xpos, xquat, B, Bc, H, total_doubles;  // H aliases [xpos, xquat, B, Bc] (dead during the QP)
+  // offsets in doubles.  zero: block of zeros; hplan / cplan: the staged H-pair and composite plans; Lb (generic QP broadcast
+  // rows) aliases S; Bc aliases the poses; H aliases [B | poses / Bc] (all dead during the QP)
+  int zero, hplan, cplan, q, tp, tq, S, F, Lb, V, bodyc, xpos, xquat, B, Bc, H, total_doubles;
 };
 
 struct IkLaunch {
@@ -661,9 +661,11 @@ __device__ __forceinline__ int box_qp(int lane, int n_act, const double *Hm, dou
 // Each lane holds its row of the group's local 16 x 16 matrix [limb x limb, limb x core; core x limb, core x core]
 // (core x core and the core rhs only in group 0, zeros in the copies).  Eliminating local pivots 0 .. nl-1 in all four groups
 // at once leaves, in every copy, minus that group's Schur contribution; one cross-group sum makes every copy the full core
-// system, which all groups then factor redundantly, so back-substitution needs no further exchange.  Per step one
-// ds_write_b64 pair (column entry, rhs) and group-addressed ds_read_b128 broadcasts; LDL' without square roots; the pivot
-// lane keeps its raw row, which is what the back-substitution consumes.  16 registers per row instead of NVP.
+// system, which all groups then factor redundantly, so back-substitution needs no further exchange.  The 16-lane groups are
+// DPP rows: pivot diagonal, rhs and column reach the rows below through v_mov_b64_dpp row_newbcast, the cross-group sum is
+// two gfx950 permlane swaps -- no LDS and no barrier inside the factorisation.  LDL' without square roots; the pivot lane
+// keeps its raw row (what the back-substitution consumes), rows below it clear their column entry so that the
+// back-substitution needs no triangle mask.  16 registers per row instead of NVP.
 template <int K>
 __device__ __forceinline__ double group_bcast(double v) {  // value of lane (lane & 48) + K: one v_mov_b64_dpp row_newbcast, no LDS
   return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xf, 0xf, true);  // every lane has a source: no 'old' value to keep
@@ -700,13 +702,12 @@ __device__ __forceinline__ void static_for_down(F &&f) {  // I = N-1 .. I
   }
 }
 
-__device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool pad, const double *Hs, double *Cb, double ci, double lo,
+__device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool pad, const double *Hs, double ci, double lo,
                                              double hi, int &status, double &x_out) {
   const int a = lane & 15;           // local row
   const int gb = lane & 48;          // first lane of my group
   const bool core_row = a >= nl;
   const bool shadow = !owner && !pad;  // copy of a core dof in groups 1..3: mirrors the owner in group 0 (lane a)
-  double *Cc = Cb, *Cr = Cb + 64;
   double x = 0.0;
   if (owner) {
     if (status == 1) x = lo;
@@ -743,7 +744,6 @@ __device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool 
     }
     // ---- elimination of local pivot k in every group; the limb pivots first, then (after the cross-group sum) the core ----
     double myinvd = 1.0;
-#if GMR_SQ_ELIM_DPP
     // pivot k of every group at once: d_k and b_k come from the pivot lane, column k (= row k by symmetry) entry by entry from
     // the lanes below it, all by row_newbcast -- no LDS, no barrier
     auto step = [&](auto K) {
@@ -764,28 +764,6 @@ __device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool 
     };
     static_for<0, 6>([&](auto K) { step(K); });  // nl >= 6 (the core has at most 10 dofs)
     static_for<6, 10>([&](auto K) { if (K < launder_uniform(nl)) step(K); });  // wave-uniform scalar branch
-#else
-    auto step = [&](const int k) {
-      Cc[lane] = R[k];  // = H^(k)[a][k] = H^(k)[k][a]
-      Cr[lane] = bb;
-      __syncthreads();
-      const double invd = fast_rcp(Cc[gb + k]);
-      const double u = a > k ? R[k] * invd : 0.0;
-      myinvd = a == k ? invd : myinvd;
-      const double bk = Cr[gb + k];
-#pragma unroll
-      for (int jj = (k + 1) & ~1; jj < 16; jj += 2) {
-        const double2 v = *reinterpret_cast<const double2 *>(Cc + gb + jj);
-        if (jj > k) { R[jj] -= u * v.x; asm volatile("" : "+v"(R[jj])); }
-        R[jj + 1] -= u * v.y;
-        asm volatile("" : "+v"(R[jj + 1]));
-      }
-      bb -= u * bk;
-    };
-#pragma unroll
-    for (int k = 0; k < 10; k++)
-      if (k < nl) step(k);  // wave-uniform
-#endif
     // every copy of the core block / rhs <- sum over the four groups
 #pragma unroll
     for (int b = 6; b < 16; b++) {  // columns 6 .. nl-1 are limb columns: already zero in the core rows, summing them is harmless
@@ -796,28 +774,13 @@ __device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool 
       const double t = group_sum4(bb);
       bb = core_row ? t : bb;
     }
-#if GMR_SQ_ELIM_DPP
     static_for<6, 10>([&](auto K) { if (K >= launder_uniform(nl)) step(K); });
     static_for<10, 16>([&](auto K) { step(K); });
-#else
-#pragma unroll
-    for (int k = 6; k < 16; k++)
-      if (k >= nl) step(k);
-#endif
     // ---- back-substitution, k = 15 .. 0: x_k = (y_k - sum_{b>k} R_k[b] x_b) / d_k ----
-#if GMR_SQ_ELIM_DPP
     static_for_down<0, 16>([&](auto K) {  // R[k] is 0 on and left of the diagonal (cleared by the elimination)
       constexpr int k = K;
       bb -= R[k] * group_bcast<k>(bb * myinvd);
     });
-#else
-    static_for_down<0, 16>([&](auto K) {
-      constexpr int k = K;
-      const double xk = group_bcast<k>(bb * myinvd);
-      const double coef = a < k ? R[k] : 0.0;
-      bb -= coef * xk;
-    });
-#endif
     const double z = bb * myinvd;
     // ratio test along x -> z over the free variables (owner lanes only).  Usually nothing blocks: decide that with compares
     // and one ballot, and only then pay for the divisions and the wave minimum.
@@ -1119,9 +1082,9 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
           const double s_lo = fmax(-prm.limit_gain * (qv - sq_rlo), -1e30), s_hi = fmin(prm.limit_gain * (sq_rhi - qv), 1e30);
           double xs;
 #ifdef GMR_DUP_PHASE
-          if (GMR_DUP_PHASE == 8) { int st2 = sq_status; double x2; (void)box_qp_struct(lane, m.sq_nlimb, sq_own, sq_pad, Hm, lds + lay.Lb, s_ci, s_lo, s_hi, st2, x2); asm volatile("" :: "v"(x2)); }
+          if (GMR_DUP_PHASE == 8) { int st2 = sq_status; double x2; (void)box_qp_struct(lane, m.sq_nlimb, sq_own, sq_pad, Hm, s_ci, s_lo, s_hi, st2, x2); asm volatile("" :: "v"(x2)); }
 #endif
-          qit = box_qp_struct(lane, m.sq_nlimb, sq_own, sq_pad, Hm, lds + lay.Lb, s_ci, s_lo, s_hi, sq_status, xs);
+          qit = box_qp_struct(lane, m.sq_nlimb, sq_own, sq_pad, Hm, s_ci, s_lo, s_hi, sq_status, xs);
           __syncthreads();
           if (sq_own) V[sq_g] = xs;  // c is dead: the same array carries dq back to the dof-indexed lanes
           __syncthreads();
