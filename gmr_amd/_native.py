@@ -14,12 +14,12 @@ from .build import LIB_PATH as _DEFAULT_LIB_PATH
 
 LIB_PATH = os.environ.get("GMR_AMD_LIB") or _DEFAULT_LIB_PATH  # override only for A/B diagnostics of variant builds
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 GMR_DTYPE_F32, GMR_DTYPE_F64 = 0, 1
 
 WORK_ITEM_DTYPE = np.dtype(
     [("frame_begin", "<i8"), ("n_burn", "<i4"), ("n_out", "<i4"), ("init_row", "<i4"), ("final_row", "<i4"),
-     ("burn_row", "<i4"), ("reserved", "<i4")], align=True
+     ("burn_row", "<i4"), ("check_stride", "<i4")], align=True
 )
 assert WORK_ITEM_DTYPE.itemsize == 32
 
@@ -33,11 +33,12 @@ class IKParams(C.Structure):
 
     _fields_ = [
         ("damping", C.c_double), ("tol", C.c_double), ("limit_gain", C.c_double), ("lm_damping", C.c_double),
-        ("max_iter", C.c_int32), ("offset_to_ground", C.c_int32), ("reserved", C.c_int32 * 2),
+        ("max_iter", C.c_int32), ("offset_to_ground", C.c_int32), ("check_tol", C.c_double),
     ]
 
-    def __init__(self, damping=0.5, tol=1e-3, limit_gain=0.95, lm_damping=1.0, max_iter=10, offset_to_ground=0):
-        super().__init__(float(damping), float(tol), float(limit_gain), float(lm_damping), int(max_iter), int(offset_to_ground))
+    def __init__(self, damping=0.5, tol=1e-3, limit_gain=0.95, lm_damping=1.0, max_iter=10, offset_to_ground=0, check_tol=1e-7):
+        super().__init__(float(damping), float(tol), float(limit_gain), float(lm_damping), int(max_iter), int(offset_to_ground),
+                         float(check_tol))
 
 
 class ModelInfo(C.Structure):
@@ -83,7 +84,7 @@ def load():
     L.gmr_last_error.argtypes = [vp]
     L.gmr_model_info_get.argtypes = [vp, C.POINTER(ModelInfo)]
     L.gmr_ik_solve.restype = C.c_int
-    L.gmr_ik_solve.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int64, vp, C.c_int, C.POINTER(IKParams), vp, vp, vp, vp,
+    L.gmr_ik_solve.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int64, vp, C.c_int, C.POINTER(IKParams), vp, vp, vp, vp, vp,
                                C.POINTER(IKStats), vp]
     L.gmr_fk.restype = C.c_int
     L.gmr_fk.argtypes = [vp, vp, vp, vp, C.c_int64, vp, vp, vp]

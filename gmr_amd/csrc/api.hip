@@ -683,7 +683,7 @@ int gmr_model_info_get(const gmr_model *m, gmr_model_info *out) {
 
 int gmr_ik_solve(gmr_model *m, const void *human_pos, const void *human_quat, int in_dtype, int n_cols, const int32_t *slot_col,
                  int64_t n_frames, const gmr_work_item *items, int n_items, const gmr_ik_params *params, const double *qpos_init,
-                 double *qpos_final, double *qpos_out, int32_t *iters_out, gmr_ik_stats *stats, void *stream) {
+                 double *qpos_final, double *qpos_out, int32_t *iters_out, int32_t *frames_done, gmr_ik_stats *stats, void *stream) {
   if (!m) return GMR_EINVAL;
   m->err.clear();
   if (m->h.nslot == 0 || (m->h.ntask[0] == 0 && m->h.ntask[1] == 0)) { set_err(m, "model has no IK config"); return GMR_ENOCONFIG; }
@@ -701,6 +701,10 @@ int gmr_ik_solve(gmr_model *m, const void *human_pos, const void *human_quat, in
       set_err(m, "work item %d covers frames outside [0,%lld)", i, (long long)n_frames);
       return GMR_EINVAL;
     }
+    if (w.check_stride < 0 || (w.check_stride > 0 && (w.burn_row < 0 || w.final_row < 0 || w.n_burn != 0))) {
+      set_err(m, "work item %d: a verification walk (check_stride) needs burn_row, final_row and n_burn = 0", i);
+      return GMR_EINVAL;
+    }
     tot += w.n_burn + w.n_out; out += w.n_out;
     need_init |= w.init_row >= 0; need_final |= w.final_row >= 0 || w.burn_row >= 0;
   }
@@ -712,19 +716,25 @@ int gmr_ik_solve(gmr_model *m, const void *human_pos, const void *human_quat, in
   HIP_TRY(m, hipSetDevice(m->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
   // longest item first so that the tail of the grid is made of short ones
-  std::vector<gmr_work_item> sorted(items, items + n_items);
-  std::stable_sort(sorted.begin(), sorted.end(), [](const gmr_work_item &a, const gmr_work_item &b) { return a.n_burn + a.n_out > b.n_burn + b.n_out; });
+  std::vector<int> order(n_items);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return items[a].n_burn + items[a].n_out > items[b].n_burn + items[b].n_out; });
+  std::vector<gmr_work_item> sorted(n_items);
+  for (int i = 0; i < n_items; ++i) sorted[i] = items[order[i]];
   const size_t items_bytes = sizeof(gmr_work_item) * (size_t)n_items, col_bytes = sizeof(int32_t) * (size_t)m->h.nslot;
-  const size_t col_off = (items_bytes + 15) & ~size_t(15);
+  const size_t order_off = (items_bytes + 15) & ~size_t(15), order_bytes = sizeof(int) * (size_t)n_items;
+  const size_t col_off = (order_off + order_bytes + 15) & ~size_t(15);
   int rc = ensure_ws(m, col_off + col_bytes);
   if (rc != GMR_OK) return rc;
   // pageable-host copies are staged by the runtime before returning, so the vectors may die after the call
   HIP_TRY(m, hipMemcpyAsync(m->ws, sorted.data(), items_bytes, hipMemcpyHostToDevice, st));
+  HIP_TRY(m, hipMemcpyAsync(static_cast<uint8_t *>(m->ws) + order_off, order.data(), order_bytes, hipMemcpyHostToDevice, st));
   HIP_TRY(m, hipMemcpyAsync(static_cast<uint8_t *>(m->ws) + col_off, slot_col, col_bytes, hipMemcpyHostToDevice, st));
 
   gmr::IkLaunch L{};
   L.hpos = human_pos; L.hquat = human_quat; L.slot_col = reinterpret_cast<const int *>(static_cast<uint8_t *>(m->ws) + col_off);
   L.items = static_cast<const gmr_work_item *>(m->ws);
+  L.order = reinterpret_cast<const int *>(static_cast<uint8_t *>(m->ws) + order_off); L.frames_done = frames_done;
   L.qinit = qpos_init; L.qfinal = qpos_final; L.qout = qpos_out; L.iters = iters_out;
   L.in_f64 = in_dtype == GMR_DTYPE_F64; L.n_cols = n_cols; L.n_items = n_items; L.prm = *params;
 #ifdef GMR_IK_STAMPS

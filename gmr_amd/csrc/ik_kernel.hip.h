@@ -118,6 +118,8 @@ struct IkLaunch {
   const void *hpos, *hquat;
   const int *slot_col;
   const gmr_work_item *items;
+  const int *order;  // [n_items] caller's index of each (length-sorted) item, for frames_done
+  int *frames_done;  // [n_items] or NULL
   const double *qinit;
   double *qfinal, *qout;
   int *iters;
@@ -883,9 +885,32 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
 
   const int nfr = w.n_burn + w.n_out;
   bool poses_valid = false;
+  // Verification walk (check_stride > 0, gmr_blob.h): the item runs down a clip whose chunks were already solved
+  // speculatively.  At every chunk boundary the state is compared with the state B that chunk started its output from: equal
+  // -> the chunk's stored frames are what a sequential run would produce, adopt its stored final state F and skip it;
+  // different -> solve the chunk here, from the true state.  kc = chunk index, left = frames left in the chunk being solved.
+  int out_done = 0, kc = 0, left = 0;
   for (int kf = 0; kf < nfr; ++kf) {
+    if (w.check_stride > 0 && left == 0) {
+      double *B = L.qfinal + (size_t)(w.burn_row + kc) * nq;
+      double d = 0.0;
+      for (int i = lane; i < nq; i += 64) d = fmax(d, fabs(q[i] - B[i]));
+      const int len = min(w.check_stride, nfr - kf);
+      if (wave_max(d) < prm.check_tol) {  // wave-uniform
+        const double *Fk = L.qfinal + (size_t)(w.final_row + kc) * nq;
+        __syncthreads();
+        for (int i = lane; i < nq; i += 64) q[i] = Fk[i];
+        __syncthreads();
+        poses_valid = false;
+        ++kc;
+        kf += len - 1;
+        continue;
+      }
+      for (int i = lane; i < nq; i += 64) B[i] = q[i];  // this chunk now starts from the state found here
+      left = len;
+    }
     const int64_t f = w.frame_begin + kf;
-    if (kf == w.n_burn && w.burn_row >= 0 && L.qfinal)  // state the first output frame starts from
+    if (w.check_stride == 0 && kf == w.n_burn && w.burn_row >= 0 && L.qfinal)  // state the first output frame starts from
       for (int i = lane; i < nq; i += 64) L.qfinal[(size_t)w.burn_row * nq + i] = q[i];
     GMR_STAMP(10);
     // ---- target preparation (update_targets: scale_human_data + offset_human_data, table-1 offsets) ----
@@ -1146,10 +1171,17 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
     if (kf >= w.n_burn) {
       for (int i = lane; i < nq; i += 64) L.qout[(size_t)f * nq + i] = q[i];
       if (L.iters && lane == 0) L.iters[f] = solves | (qpflag << 30);
+      ++out_done;
+      if (w.check_stride > 0 && --left == 0) {  // a chunk solved here: its final state
+        double *Fk = L.qfinal + (size_t)(w.final_row + kc) * nq;
+        for (int i = lane; i < nq; i += 64) Fk[i] = q[i];
+        ++kc;
+      }
     }
     __syncthreads();
   }
-  if (w.final_row >= 0 && L.qfinal)
+  if (L.frames_done && lane == 0) L.frames_done[L.order[blockIdx.x]] = out_done;
+  if (w.check_stride == 0 && w.final_row >= 0 && L.qfinal)
     for (int i = lane; i < nq; i += 64) L.qfinal[(size_t)w.final_row * nq + i] = q[i];
 #ifdef GMR_IK_STAMPS
   if (lane == 0 && L.dbg)

@@ -69,10 +69,11 @@ class Engine:
     def ik_solve(self, pos: torch.Tensor, quat: torch.Tensor, slot_col: np.ndarray, items: np.ndarray,
                  params: Optional[IKParams] = None, qpos_init: Optional[torch.Tensor] = None, n_final: int = 0,
                  want_iters: bool = True, out: Optional[torch.Tensor] = None, qpos_final: Optional[torch.Tensor] = None,
-                 iters: Optional[torch.Tensor] = None):
+                 iters: Optional[torch.Tensor] = None, frames_done: Optional[torch.Tensor] = None):
         """pos [N,B,3], quat [N,B,4] (float32 or float64 CUDA tensors) -> qpos [N,nq] float64.
 
         Frames not covered by any item's output range are left as NaN.  Returns (qpos, iters or None, qpos_final or None).
+        ``frames_done`` (int32 [n_items] on the device) receives the output frames each item solved (repair runs, gmr_blob.h).
         """
         if pos.device != self.device or quat.device != self.device:
             raise EngineError("inputs must live on the engine's device")
@@ -107,8 +108,13 @@ class Engine:
                 qpos_init = qpos_init.contiguous()
             if len(items) and int(items["init_row"].max()) >= qpos_init.shape[0]:
                 raise EngineError("init_row outside qpos_init")
-        if len(items) and int(max(items["final_row"].max(), items["burn_row"].max())) >= n_final:
-            raise EngineError("final_row outside qpos_final")
+        if len(items):
+            reach = np.where(items["check_stride"] > 0, (np.maximum(items["n_out"], 1) - 1) // np.maximum(items["check_stride"], 1), 0)
+            if int(max((items["final_row"] + reach).max(), (items["burn_row"] + reach).max())) >= n_final:
+                raise EngineError("final_row outside qpos_final")
+        if frames_done is not None and (frames_done.dtype != torch.int32 or frames_done.device != self.device or not frames_done.is_contiguous()
+                                        or frames_done.numel() < len(items)):
+            raise EngineError("frames_done must be a contiguous int32 [n_items] tensor on the engine's device")
         stats = IKStats()
         self.last_stats = stats
         if N == 0 or len(items) == 0:  # nothing to launch (empty tensors have no device pointer)
@@ -116,71 +122,48 @@ class Engine:
         rc = self._lib.gmr_ik_solve(
             self._h, _ptr(pos), _ptr(quat), _native.GMR_DTYPE_F64 if pos.dtype == torch.float64 else _native.GMR_DTYPE_F32, B,
             slot_col.ctypes.data_as(C.c_void_p), N, items.ctypes.data_as(C.c_void_p), len(items), C.byref(prm), _ptr(qpos_init),
-            _ptr(qfin), _ptr(out), _ptr(iters), C.byref(stats), self._stream())
+            _ptr(qfin), _ptr(out), _ptr(iters), _ptr(frames_done), C.byref(stats), self._stream())
         self._check(rc, "gmr_ik_solve")
         self.last_stats = stats
         return out, iters, qfin
 
     def ik_solve_chunked(self, pos: torch.Tensor, quat: torch.Tensor, slot_col: np.ndarray, seq_offsets, chunk: int, burn_in: int,
-                         params: Optional[IKParams] = None, eps: float = 1e-7, max_passes: int = 64):
-        """Parallel-in-time solve of long clips with *verified* chunk boundaries.
+                         params: Optional[IKParams] = None, eps: float = 1e-7):
+        """Parallel-in-time solve of long clips with *verified* chunk boundaries, in two launches.
 
-        Pass 0 solves every chunk of ``chunk`` frames concurrently, each (but a clip's first) warmed up over
-        ``burn_in`` earlier frames from ``qpos0``.  A chunk is accepted only if the state its first output frame
-        started from equals its predecessor's final state to ``eps`` and the predecessor is accepted; runs of
-        rejected chunks are re-solved sequentially from the accepted predecessor's final state (exact continuation),
-        and the check repeats.  The result therefore follows the reference's sequential warm-start semantics to
-        ``eps`` regardless of how well the burn-in worked; burn-in quality only decides how much is re-solved.
-        Returns (qpos [N,nq], iters [N], info dict).
+        Launch 1 solves every chunk of ``chunk`` frames concurrently, each (but a clip's first) warmed up over
+        ``burn_in`` earlier frames from ``qpos0``, and records per chunk the state B its first output frame started from
+        and its final state F.  Launch 2 is one *verification walk* per clip (``gmr_work_item.check_stride``): starting
+        from the exact first chunk it compares, boundary by boundary, the true state with the next chunk's B; if they
+        agree to ``eps`` the chunk's stored frames are what the sequential run produces and the walk jumps to its F,
+        otherwise it solves that chunk itself from the true state.  The result therefore follows the reference's
+        sequential warm-start semantics to ``eps`` however good the burn-in was; burn-in quality only decides how much
+        of a clip the walk has to re-solve (clips that settle in one IK basin verify almost for free, clips that keep
+        switching basins degrade to the sequential rate).  Returns (qpos [N,nq], iters [N], info dict).
         """
         from .schedule import make_items
         offs = np.asarray(seq_offsets, dtype=np.int64)
         items = make_items(offs, chunk=chunk, burn_in=burn_in, track=True)
         n = len(items)
-        out, iters, qf = self.ik_solve(pos, quat, slot_col, items, params=params, n_final=2 * n)
-        info = {"chunks": n, "passes": 0, "resolved_frames": 0, "first_pass_rejected": 0}
+        prm = params or IKParams()
+        prm = IKParams(prm.damping, prm.tol, prm.limit_gain, prm.lm_damping, prm.max_iter, prm.offset_to_ground, eps)
+        out, iters, qf = self.ik_solve(pos, quat, slot_col, items, params=prm, n_final=2 * n)
+        info = {"chunks": n, "passes": 0, "resolved_frames": 0}
         if n == 0:
             return out, iters, info
         out_begin = items["frame_begin"] + items["n_burn"]
-        is_first = np.isin(out_begin, offs[:-1])
-        pred = np.arange(n) - 1
-        cons_idx = torch.from_numpy(np.nonzero(~is_first)[0]).to(self.device)
-        pred_idx = torch.from_numpy(pred[~is_first]).to(self.device)
-        accepted = is_first.copy()  # exact by construction: a clip's first chunk, and every chunk of a re-solved run
-        for p in range(max_passes + 1):
-            cons = np.ones(n, dtype=bool)
-            if len(cons_idx):
-                d = (qf[n + cons_idx] - qf[pred_idx]).abs().amax(dim=1)
-                cons[~is_first] = (d < eps).cpu().numpy()
-            runs = []  # maximal runs [i, j) of rejected chunks directly behind an accepted one
-            i = 0
-            while i < n:
-                if accepted[i]:
-                    i += 1
-                elif accepted[i - 1] and cons[i]:
-                    accepted[i] = True
-                    i += 1
-                elif accepted[i - 1]:
-                    j = i + 1
-                    while j < n and not accepted[j] and not cons[j]:
-                        j += 1
-                    runs.append((i, j))
-                    i = j
-                else:  # predecessor not accepted yet: decided in a later pass
-                    i += 1
-            if p == 0:
-                info["first_pass_rejected"] = int(sum(j - i for i, j in runs))
-            if accepted.all():
-                break
-            if not runs or p == max_passes:
-                raise EngineError("chunk verification did not converge")
-            redo = np.zeros(len(runs), dtype=_native.WORK_ITEM_DTYPE)
-            for k, (i, j) in enumerate(runs):
-                redo[k] = (out_begin[i], 0, int(items["n_out"][i:j].sum()), i - 1, j - 1, n + i, 0)
-                info["resolved_frames"] += int(redo[k]["n_out"])
-                accepted[i:j] = True
-            self.ik_solve(pos, quat, slot_col, redo, params=params, qpos_init=qf, qpos_final=qf, out=out, iters=iters)
-            info["passes"] += 1
+        first = np.nonzero(np.isin(out_begin, offs[:-1]))[0]          # first chunk of every (non-empty) clip
+        last = np.append(first[1:], n)                                  # one past its last chunk
+        multi = last - first > 1
+        walks = np.zeros(int(multi.sum()), dtype=_native.WORK_ITEM_DTYPE)
+        for k, (c0, c1) in enumerate(zip(first[multi], last[multi])):
+            clip_end = offs[np.searchsorted(offs, out_begin[c0], side="right")]
+            walks[k] = (out_begin[c0 + 1], 0, int(clip_end - out_begin[c0 + 1]), c0, c0 + 1, n + c0 + 1, chunk)
+        if len(walks):
+            done = torch.zeros(len(walks), dtype=torch.int32, device=self.device)
+            self.ik_solve(pos, quat, slot_col, walks, params=prm, qpos_init=qf, qpos_final=qf, out=out, iters=iters, frames_done=done)
+            info["resolved_frames"] = int(done.sum().item())
+            info["passes"] = 1
         return out, iters, info
 
     def evaluate(self, qpos: torch.Tensor, pos: Optional[torch.Tensor] = None, quat: Optional[torch.Tensor] = None,

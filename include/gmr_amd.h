@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define GMR_ABI_VERSION 1
+#define GMR_ABI_VERSION 2
 
 #define GMR_OK 0
 #define GMR_EINVAL (-1)    /* bad argument / blob / shape                     */
@@ -97,12 +97,14 @@ int gmr_model_info_get(const gmr_model *m, gmr_model_info *out);
  *   qpos_out   device, [n_frames][nq] f64; only frames covered by an item's n_out are written
  *   iters_out  device, [n_frames] int32 or NULL: solve_ik calls spent on the frame
  *              (bit 30 set if a QP hit its iteration cap -- never expected)
+ *   frames_done device, [n_items] int32 or NULL: output frames each item solved (n_out unless a
+ *              check_stride item stopped early, see gmr_blob.h)
  *   stream     hipStream_t (as void*), NULL = default stream.  The call is
  *              asynchronous with respect to the host.                             */
 int gmr_ik_solve(gmr_model *m, const void *human_pos, const void *human_quat, int in_dtype, int n_cols,
                  const int32_t *slot_col, int64_t n_frames, const gmr_work_item *items, int n_items,
                  const gmr_ik_params *params, const double *qpos_init, double *qpos_final, double *qpos_out,
-                 int32_t *iters_out, gmr_ik_stats *stats, void *stream);
+                 int32_t *iters_out, int32_t *frames_done, gmr_ik_stats *stats, void *stream);
 
 /* Single-sequence sessions ("teleop"): one frame per call, warm start carried in the session -- the semantics of calling
  * GeneralMotionRetargeting.retarget once per captured frame (motion_retarget.py:139-185).  Inputs and outputs are HOST

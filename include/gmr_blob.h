@@ -72,6 +72,14 @@ typedef struct gmr_blob_header {
  * time order with warm start.  The first n_burn frames only warm the state up
  * (no output); the following n_out frames write qpos_out[frame].  burn_row lets a
  * caller check a chunk's warm-up against its predecessor's final state.
+ * check_stride > 0 makes the item a *verification walk* down a clip whose chunks
+ * of check_stride frames were already solved speculatively (n_burn must be 0):
+ * at the k-th chunk boundary (k = 0, 1, ...) the state is compared with
+ * qpos_final[burn_row + k], the state that chunk started its own output from.
+ * Equal to gmr_ik_params.check_tol: the chunk's stored frames stand, the walk adopts
+ * qpos_final[final_row + k] (its stored final state) and skips it.  Different: the
+ * chunk is solved here from the true state, qpos_final[burn_row + k] and
+ * qpos_final[final_row + k] are rewritten.  frames_done[item] = frames solved.
  * init_row >= 0 starts from qpos_init[init_row], otherwise from qpos0
  * (reference: a fresh GeneralMotionRetargeting per clip, motion_retarget.py:75). */
 typedef struct gmr_work_item {
@@ -82,7 +90,7 @@ typedef struct gmr_work_item {
   int32_t final_row;   /* row of qpos_final to receive the last state, or -1   */
   int32_t burn_row;    /* row of qpos_final to receive the state right before  */
                        /* the first output frame (after burn-in), or -1        */
-  int32_t reserved;
+  int32_t check_stride; /* 0: plain item                                        */
 } gmr_work_item;
 
 /* Solver constants; defaults are the reference's hard-coded values. */
@@ -93,7 +101,7 @@ typedef struct gmr_ik_params {
   double lm_damping;      /* 1.0    motion_retarget.py:88,105                  */
   int32_t max_iter;       /* 10     motion_retarget.py:56                      */
   int32_t offset_to_ground; /* 0    motion_retarget.py:122,252-270             */
-  int32_t reserved[2];
+  double check_tol;       /* 1e-7   max |dq| for a repair run to stop (check_stride) */
 } gmr_ik_params;
 
 #ifdef __cplusplus

@@ -603,7 +603,7 @@ static void gather_frame(const void *pos, const void *quat, int in_f64, int n_co
  * n_threads > 1 runs items on that many OpenMP threads (clip-parallel CPU baseline). */
 int oracle_ik_solve(const oracle_model *m, const gmr_ik_params *prm, const void *pos, const void *quat, int in_f64, int n_cols,
                     const int32_t *slot_col, const gmr_work_item *items, int n_items, const double *qpos_init, double *qpos_final,
-                    double *qpos_out, int32_t *iters_out, int n_threads) {
+                    double *qpos_out, int32_t *iters_out, int32_t *frames_done, int n_threads) {
   int nq = m->h.nq, ns = m->h.nslot, fail = 0;
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads > 0 ? n_threads : 1) reduction(| : fail)
@@ -612,18 +612,38 @@ int oracle_ik_solve(const oracle_model *m, const gmr_ik_params *prm, const void 
     const gmr_work_item *w = items + it;
     double q[MAXV + 1], hp[3 * MAXS], hq[4 * MAXS];
     memcpy(q, w->init_row >= 0 ? qpos_init + (size_t)w->init_row * nq : m->qpos0, nq * sizeof(double));
-    for (int k = 0; k < w->n_burn + w->n_out; k++) {
+    int out_done = 0, kc = 0, left = 0, nfr = w->n_burn + w->n_out;
+    for (int k = 0; k < nfr; k++) {
+      if (w->check_stride > 0 && left == 0) { /* verification walk (gmr_blob.h): adopt a consistent chunk, solve an inconsistent one */
+        double *B = qpos_final + (size_t)(w->burn_row + kc) * nq, d = 0.0;
+        int len = w->check_stride < nfr - k ? w->check_stride : nfr - k;
+        for (int i = 0; i < nq; i++) d = fmax(d, fabs(q[i] - B[i]));
+        if (d < prm->check_tol) {
+          memcpy(q, qpos_final + (size_t)(w->final_row + kc) * nq, nq * sizeof(double));
+          kc++;
+          k += len - 1;
+          continue;
+        }
+        memcpy(B, q, nq * sizeof(double));
+        left = len;
+      }
       int64_t f = w->frame_begin + k;
-      if (k == w->n_burn && w->burn_row >= 0 && qpos_final) memcpy(qpos_final + (size_t)w->burn_row * nq, q, nq * sizeof(double));
+      if (w->check_stride == 0 && k == w->n_burn && w->burn_row >= 0 && qpos_final) memcpy(qpos_final + (size_t)w->burn_row * nq, q, nq * sizeof(double));
       gather_frame(pos, quat, in_f64, n_cols, slot_col, ns, f, hp, hq);
       int s = oracle_retarget_frame(m, prm, q, hp, hq, NULL);
       if (s < 0) fail |= 1;
       if (k >= w->n_burn) {
         memcpy(qpos_out + (size_t)f * nq, q, nq * sizeof(double));
         if (iters_out) iters_out[f] = s;
+        out_done++;
+        if (w->check_stride > 0 && --left == 0) {
+          memcpy(qpos_final + (size_t)(w->final_row + kc) * nq, q, nq * sizeof(double));
+          kc++;
+        }
       }
     }
-    if (w->final_row >= 0 && qpos_final) memcpy(qpos_final + (size_t)w->final_row * nq, q, nq * sizeof(double));
+    if (frames_done) frames_done[it] = out_done;
+    if (w->check_stride == 0 && w->final_row >= 0 && qpos_final) memcpy(qpos_final + (size_t)w->final_row * nq, q, nq * sizeof(double));
   }
   (void)n_threads;
   return fail ? -1 : 0;

@@ -22,16 +22,16 @@ class IKParams(C.Structure):
 
     _fields_ = [
         ("damping", C.c_double), ("tol", C.c_double), ("limit_gain", C.c_double), ("lm_damping", C.c_double),
-        ("max_iter", C.c_int32), ("offset_to_ground", C.c_int32), ("reserved", C.c_int32 * 2),
+        ("max_iter", C.c_int32), ("offset_to_ground", C.c_int32), ("check_tol", C.c_double),
     ]
 
-    def __init__(self, damping=0.5, tol=1e-3, limit_gain=0.95, lm_damping=1.0, max_iter=10, offset_to_ground=0):
-        super().__init__(damping, tol, limit_gain, lm_damping, max_iter, int(offset_to_ground))
+    def __init__(self, damping=0.5, tol=1e-3, limit_gain=0.95, lm_damping=1.0, max_iter=10, offset_to_ground=0, check_tol=1e-7):
+        super().__init__(damping, tol, limit_gain, lm_damping, max_iter, int(offset_to_ground), check_tol)
 
 
 WORK_ITEM_DTYPE = np.dtype(
     [("frame_begin", "<i8"), ("n_burn", "<i4"), ("n_out", "<i4"), ("init_row", "<i4"), ("final_row", "<i4"),
-     ("burn_row", "<i4"), ("reserved", "<i4")], align=True
+     ("burn_row", "<i4"), ("check_stride", "<i4")], align=True
 )
 
 
@@ -64,7 +64,7 @@ def lib():
         L.oracle_retarget_frame.restype = C.c_int
         L.oracle_retarget_frame.argtypes = [vp, C.POINTER(IKParams), dp, dp, dp, dp]
         L.oracle_ik_solve.restype = C.c_int
-        L.oracle_ik_solve.argtypes = [vp, C.POINTER(IKParams), vp, vp, C.c_int, C.c_int, ip, vp, C.c_int, dp, dp, dp, ip, C.c_int]
+        L.oracle_ik_solve.argtypes = [vp, C.POINTER(IKParams), vp, vp, C.c_int, C.c_int, ip, vp, C.c_int, dp, dp, dp, ip, ip, C.c_int]
         L.oracle_fk_kin.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int64,
                                     C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.oracle_stage_error.restype = C.c_double
@@ -173,7 +173,8 @@ class Oracle:
             raise RuntimeError("oracle QP failed")
         return q, s, errs
 
-    def ik_solve(self, pos, quat, slot_col, items, qpos_init=None, params=None, n_threads=1, want_final=False):
+    def ik_solve(self, pos, quat, slot_col, items, qpos_init=None, params=None, n_threads=1, want_final=False, qpos_final=None,
+                 want_done=False):
         """Batch solve with the work-item semantics of ``gmr_ik_solve``.
 
         pos ``[N, n_cols, 3]``, quat ``[N, n_cols, 4]`` (float32 or float64, same dtype),
@@ -191,14 +192,17 @@ class Oracle:
         qi = _c64(qpos_init) if qpos_init is not None else None
         nfin = int(max(items["final_row"].max(), items["burn_row"].max())) + 1 if len(items) else 0
         qf = np.zeros((max(nfin, 1), self.nq)) if want_final else None
+        if qpos_final is not None:  # caller-owned rows (repair runs read the stored chunk states from them)
+            qf = qpos_final
+        done = np.zeros(len(items), dtype=np.int32)
         rc = lib().oracle_ik_solve(
             self._h, C.byref(prm), pos.ctypes.data, quat.ctypes.data, int(pos.dtype == np.float64), n_cols, _i(slot_col),
             items.ctypes.data, len(items), _d(qi) if qi is not None else None, _d(qf) if qf is not None else None,
-            _d(qout), _i(iters), int(n_threads),
+            _d(qout), _i(iters), _i(done), int(n_threads),
         )
         if rc != 0:
             raise RuntimeError("oracle QP failed")
-        return qout, iters, qf
+        return (qout, iters, qf, done) if want_done else (qout, iters, qf)
 
 
 def box_qp(H, c, lo, hi):

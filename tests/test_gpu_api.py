@@ -188,7 +188,7 @@ def test_bad_arguments_are_rejected():
     assert torch.isnan(out).all()
     import ctypes
     prm = __import__("gmr_amd._native", fromlist=["IKParams"]).IKParams()
-    rc = eng._lib.gmr_ik_solve(eng._h, None, None, 0, 14, sc.ctypes.data_as(ctypes.c_void_p), 4, None, 0, ctypes.byref(prm), None, None, None, None, None, None)
+    rc = eng._lib.gmr_ik_solve(eng._h, None, None, 0, 14, sc.ctypes.data_as(ctypes.c_void_p), 4, None, 0, ctypes.byref(prm), None, None, None, None, None, None, None)
     assert rc == -1 and b"null" in eng._lib.gmr_last_error(eng._h)  # the C ABI itself rejects null buffers
 
 
@@ -439,3 +439,44 @@ def test_session_single_sequence_mode_matches_oracle():
     rev = list(reversed(sub))
     d = {n: (pos[4][names.index(n)], quat[4][names.index(n)]) for n in rev}
     assert np.abs(g.retarget(d) - q_ref[4]).max() < 1e-6 and len(g._sessions) == 2
+
+
+def test_verification_walk_matches_oracle():
+    """check_stride work items through the C ABI: same speculative chunks, same walk, same adopted / re-solved chunks
+    (frames_done), same stored states and the sequential result at the end -- GPU against the oracle's restatement."""
+    from gmr_amd.engine import Engine
+    from gmr_amd._native import IKParams, WORK_ITEM_DTYPE as W
+    cm = compiled("smplx", "unitree_g1")
+    eng, orc = Engine(cm), Oracle(cm.blob)
+    pos, quat, names, offs, _ = synth.synth_clips(cm, 3, 120, seed=13, hard=True, dtype=np.float32)
+    sc = cm.slot_columns(names)
+    chunk, burn = 8, 8
+    items = make_items(offs, chunk=chunk, burn_in=burn, track=True)
+    n = len(items)
+    ob = items["frame_begin"] + items["n_burn"]
+    walks = np.zeros(3, W)
+    for c in range(3):
+        c0 = int(np.nonzero(ob == offs[c])[0][0])
+        walks[c] = (ob[c0 + 1], 0, int(offs[c + 1] - ob[c0 + 1]), c0, c0 + 1, n + c0 + 1, chunk)
+    # oracle
+    qf_o = np.zeros((2 * n, orc.nq))
+    q_o, it_o, _ = orc.ik_solve(pos, quat, sc, items, qpos_final=qf_o)
+    q_w, it_w, _, done_o = orc.ik_solve(pos, quat, sc, walks, qpos_init=qf_o.copy(), qpos_final=qf_o, want_done=True)
+    m = ~np.isnan(q_w[:, 0])
+    q_o[m], it_o[m] = q_w[m], it_w[m]
+    # GPU
+    tp, tq = torch.from_numpy(pos).to(eng.device), torch.from_numpy(quat).to(eng.device)
+    q_g, it_g, qf_g = eng.ik_solve(tp, tq, sc, items, n_final=2 * n)
+    done_g = torch.zeros(3, dtype=torch.int32, device=eng.device)
+    eng.ik_solve(tp, tq, sc, walks, qpos_init=qf_g, qpos_final=qf_g, out=q_g, iters=it_g, frames_done=done_g)
+    assert np.array_equal(done_g.cpu().numpy(), done_o) and 0 < done_o.sum() < 3 * 112
+    assert np.abs(q_g.cpu().numpy() - q_o).max() < 1e-6 and np.array_equal((it_g & 0x3FFFFFFF).cpu().numpy(), it_o)
+    assert np.abs(qf_g.cpu().numpy() - qf_o).max() < 1e-6
+    q_seq, it_seq, _ = orc.ik_solve(pos, quat, sc, make_items(offs))
+    assert np.abs(q_g.cpu().numpy() - q_seq).max() < 1e-6 and np.array_equal((it_g & 0x3FFFFFFF).cpu().numpy(), it_seq)
+    # the packaged form
+    q_c, it_c, info = eng.ik_solve_chunked(tp, tq, sc, offs, chunk=chunk, burn_in=burn)
+    assert torch.equal(q_c, q_g) and info["resolved_frames"] == int(done_o.sum())
+    with pytest.raises(Exception):
+        bad = walks.copy(); bad["n_burn"] = 1
+        eng.ik_solve(tp, tq, sc, bad, qpos_init=qf_g, qpos_final=qf_g)

@@ -213,6 +213,33 @@ def test_work_item_semantics_chunk_equals_sequential_prefix():
     np.testing.assert_array_equal(q_c[15:], q_seq[15:])
 
 
+def test_verification_walk_equals_sequential():
+    """check_stride items (gmr_blob.h): chunks solved from a deliberately poor burn-in, then one walk per clip that adopts the
+    consistent chunks and re-solves the others -- the result is the sequential run, whatever the burn-in did."""
+    from gmr_amd.schedule import make_items as sched_items
+    cm = compiled("smplx", "unitree_g1")
+    orc = Oracle(cm.blob)
+    pos, quat, names, offs, _ = synth.synth_clips(cm, 2, 90, seed=13, hard=True, dtype=np.float64)
+    sc = cm.slot_columns(names)
+    q_seq, it_seq, _ = orc.ik_solve(pos, quat, sc, make_items(offs, WORK_ITEM_DTYPE))
+    chunk, burn = 8, 8
+    items = np.ascontiguousarray(sched_items(offs, chunk=chunk, burn_in=burn, track=True), dtype=WORK_ITEM_DTYPE)
+    n = len(items)
+    qf = np.zeros((2 * n, orc.nq))
+    q0, it0, _ = orc.ik_solve(pos, quat, sc, items, qpos_final=qf)
+    out_begin = items["frame_begin"] + items["n_burn"]
+    assert np.abs(q0 - q_seq).max() > 1e-3  # a short burn-in from qpos0 is not enough: the speculative chunks are wrong somewhere
+    walks = np.zeros(2, WORK_ITEM_DTYPE)
+    for c in range(2):
+        c0 = int(np.nonzero(out_begin == offs[c])[0][0])
+        walks[c] = (out_begin[c0 + 1], 0, int(offs[c + 1] - out_begin[c0 + 1]), c0, c0 + 1, n + c0 + 1, chunk)
+    q1, it1, _, done = orc.ik_solve(pos, quat, sc, walks, qpos_init=qf.copy(), qpos_final=qf, want_done=True)
+    solved = ~np.isnan(q1[:, 0])
+    q0[solved], it0[solved] = q1[solved], it1[solved]
+    assert np.abs(q0 - q_seq).max() < 1e-6 and np.array_equal(it0, it_seq)
+    assert 0 < done.sum() < 2 * 90 - 2 * chunk and int(solved.sum()) == int(done.sum())  # some chunks adopted, some re-solved
+
+
 def test_offset_to_ground_and_height_ratio():
     cm = compiled("bvh", "unitree_g1", 1.6)
     assert abs(cm.ratio - 1.6 / cm.config.human_height_assumption) < 1e-15
