@@ -213,6 +213,15 @@ def main():
             lat = np.array(lat[16:]) * 1e6
             result["live_session"] = {"frames": int(lat.size), "median_latency_us": float(np.median(lat)), "p99_latency_us": float(np.quantile(lat, 0.99)),
                                       "frames_per_s": float(1e6 / lat.mean()), "includes": "host staging + launch + kernel + sync, one wavefront"}
+            # the same path fed from / returned to pageable host arrays (what retarget_batch does for numpy callers): PCIe inclusive
+            nh = min(S, 512) * T
+            hp_all, hq_all = pos[:nh].cpu().numpy(), quat[:nh].cpu().numpy()
+            h_items = make_items(offs[: nh // T + 1])
+            def host_fed():
+                q_h, _, _ = eng.ik_solve(torch.from_numpy(hp_all).to(dev), torch.from_numpy(hq_all).to(dev), sc, h_items, want_iters=False)
+                return q_h.cpu().numpy()
+            t_host, _ = timed(host_fed, reps=3)
+            result["host_fed"] = {"frames": nh, "frames_per_s": nh / t_host, "includes": "H2D of the key-points (392 B/frame) + kernel + D2H of qpos (288 B/frame), pageable host memory, no overlap"}
             result["single_clip"] = {
                 "frames": T, "sequential_frames_per_s": T / t_seq, "verified_chunked_frames_per_s": T / t_chk,
                 "chunk": 8, "burn_in": 24, "passes": info["passes"], "resolved_frames": info["resolved_frames"],

@@ -1131,6 +1131,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         GMR_STAMP(8);
 #ifdef GMR_IK_STAMPS
         stamp_acc[15] += (u64)(qit < 0 ? -qit : qit);  // QP iterations (not cycles)
+        if constexpr (SQ) stamp_acc[14] += __ballot(sq_own && sq_status != 0) ? 1 : 0;  // solves that end with a non-empty working set
 #endif
         // ---- integrate (mj_integratePos) ----
         {

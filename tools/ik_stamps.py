@@ -35,6 +35,7 @@ v = np.array(list(out), dtype=np.float64)
 names_ = ["prep", "fk", "residual", "task_block", "screws", "composites", "F_c_limits", "H_assemble", "box_qp", "integrate", "output"]
 solves = float((it & 0x3FFFFFFF).sum().item())
 qp_iters = v[15]; v[15] = 0
-print(f"total solves {solves:.0f}; QP iterations per solve {qp_iters / solves:.3f}; cycles per solve per wave: {v.sum() / solves:.0f}")
+with_ws = v[14]; v[14] = 0
+print(f"total solves {solves:.0f}; QP iterations per solve {qp_iters / solves:.3f}; solves ending with active bounds {with_ws / solves:.3f}; cycles per solve per wave: {v.sum() / solves:.0f}")
 for n, x in zip(names_, v):
     print(f"  {n:12s} {100 * x / v.sum():6.2f} %   {x / solves:9.0f} cyc/solve")
