@@ -58,8 +58,9 @@ def motions_from_qpos(gmr: GeneralMotionRetargeting, qpos: torch.Tensor, seq_off
     out = []
     for s in range(len(offs) - 1):
         a, b = int(offs[s]), int(offs[s + 1])
-        out.append({"fps": fps_list[s], "root_pos": rp[a:b].copy(), "root_rot": rr[a:b].copy(), "dof_pos": dp[a:b].copy(),
-                    "local_body_pos": lb[a:b].copy(), "link_body_list": names})
+        # row slices of the batch arrays (C-contiguous views): no second host copy; pickling a slice stores only the slice
+        out.append({"fps": fps_list[s], "root_pos": rp[a:b], "root_rot": rr[a:b], "dof_pos": dp[a:b],
+                    "local_body_pos": lb[a:b], "link_body_list": names})
     return out
 
 
