@@ -24,7 +24,7 @@ WORK_ITEM_DTYPE = np.dtype(
 assert WORK_ITEM_DTYPE.itemsize == 32
 
 EXPORTS = ["gmr_abi_version", "gmr_model_create", "gmr_model_destroy", "gmr_last_error", "gmr_model_info_get",
-           "gmr_ik_solve", "gmr_fk", "gmr_fk_min_height", "gmr_bvh_fk", "gmr_evaluate", "gmr_smplx_keypoints",
+           "gmr_ik_solve", "gmr_fk", "gmr_fk_min_height", "gmr_bvh_fk", "gmr_bvh_parse_motion", "gmr_evaluate", "gmr_smplx_keypoints",
            "gmr_session_create", "gmr_session_destroy", "gmr_session_reset", "gmr_session_step", "gmr_session_state"]
 
 
@@ -96,6 +96,8 @@ def load():
     L.gmr_smplx_keypoints.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int64, C.c_int64, C.c_int, vp, vp, vp]
     L.gmr_bvh_fk.restype = C.c_int
     L.gmr_bvh_fk.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_int64, C.c_double, vp, vp, vp]
+    L.gmr_bvh_parse_motion.restype = C.c_int64
+    L.gmr_bvh_parse_motion.argtypes = [C.c_char_p, C.c_size_t, C.c_int64, vp, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.gmr_session_create.restype = vp
     L.gmr_session_create.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(IKParams)]
     L.gmr_session_destroy.argtypes = [vp]

@@ -3,8 +3,9 @@
 Mirror of ``load_lafan1_file`` (reference general_motion_retargeting/utils/lafan1.py:8-71) with the reference's
 own file semantics (``read_bvh``, utils/lafan_vendor/extract.py:43-166): hierarchy parsed line by line, the Euler
 order taken from the first CHANNELS line, the channel count from the last one, root translation from the first three
-motion columns, non-root local positions = joint offsets.  The text is parsed on the host (numpy's C tokenizer for the
-motion block); Euler -> quaternion, the quaternion FK, the Y-up -> Z-up turn, cm -> m and the ``LeftFootMod`` /
+motion columns, non-root local positions = joint offsets.  The hierarchy (a few dozen lines) is parsed in Python; the
+MOTION block -- the bulk of the file, and the regex + float() loop that dominates loading in the reference -- goes through
+the library's native parser (``gmr_bvh_parse_motion``, correctly rounded like ``float()``); Euler -> quaternion, the quaternion FK, the Y-up -> Z-up turn, cm -> m and the ``LeftFootMod`` /
 ``RightFootMod`` synthesis run in one HIP kernel (``gmr_bvh_fk``) and the result stays on the GPU as the
 ``[T, B, 3]`` / ``[T, B, 4]`` tensors ``retarget_batch`` consumes -- no per-frame dicts unless asked for.
 
@@ -36,9 +37,31 @@ class BvhAnim:
         self.frametime = frametime
 
 
+def _parse_motion(block: bytes, fnum: int, max_cols: int, filename: str) -> np.ndarray:
+    """The first ``fnum`` non-empty lines of the motion block as a float64 ``[fnum, columns]`` array (native parser).
+    ``max_cols`` bounds the row length (the hierarchy fixes it); longer rows are reported as malformed."""
+    lib = _native.load()
+    cap = fnum * max_cols + 1
+    out = np.empty(cap, dtype=np.float64)
+    n_lines, n_cols = C.c_int64(0), C.c_int64(0)
+    n = lib.gmr_bvh_parse_motion(block, len(block), fnum, out.ctypes.data, cap, C.byref(n_lines), C.byref(n_cols))
+    if n < 0:
+        raise ValueError(f"{filename}: malformed motion block (bad number or ragged rows)")
+    if n_lines.value < fnum:
+        raise ValueError(f"{filename}: {n_lines.value} motion rows, header says {fnum}")
+    return out[:n].reshape(fnum, n_cols.value)
+
+
 def read_bvh(filename: str) -> BvhAnim:
-    with open(filename, "r") as f:
-        lines = f.read().split("\n")
+    with open(filename, "rb") as f:
+        raw = f.read()
+    cut = raw.find(b"Frame Time:")
+    if cut < 0:
+        raise ValueError(f"{filename}: not a BVH file this loader understands")
+    eol = raw.find(b"\n", cut)
+    eol = len(raw) if eol < 0 else eol + 1
+    lines = raw[:eol].decode("utf-8", errors="replace").split("\n")  # the header, up to and including the Frame Time line
+    motion_block = raw[eol:]
     names: List[str] = []
     offsets: List[List[float]] = []
     parents: List[int] = []
@@ -92,10 +115,7 @@ def read_bvh(filename: str) -> BvhAnim:
     if fnum is None or order is None or channels is None or not names:
         raise ValueError(f"{filename}: not a BVH file this loader understands")
     J = len(names)
-    body = [ln for ln in lines[i:] if ln.strip()]
-    if len(body) < fnum:
-        raise ValueError(f"{filename}: {len(body)} motion rows, header says {fnum}")
-    data = np.array(" ".join(body[:fnum]).split(), dtype=np.float64).reshape(fnum, -1)
+    data = _parse_motion(motion_block, fnum, 9 * J + 3, filename)  # the ctypes call releases the GIL: files parse in parallel threads
     offs = np.asarray(offsets, dtype=np.float64)
     positions = np.repeat(offs[None], fnum, axis=0)
     if channels == 3:

@@ -940,6 +940,81 @@ int gmr_smplx_keypoints(const int32_t *parents, int n_joints, int joints_stride,
   return hipGetLastError() == hipSuccess ? GMR_OK : GMR_EDEVICE;
 }
 
+int64_t gmr_bvh_parse_motion(const char *text, size_t len, int64_t max_lines, double *out, int64_t max_out, int64_t *n_lines,
+                             int64_t *n_cols) {
+  // Decimal -> double by Clinger's fast path: a mantissa below 2^53 and a power of ten up to 10^22 are both exact doubles, so
+  // one multiply / divide gives the correctly rounded result (what Python's float() returns).  Anything else (more than 19
+  // digits, huge exponents, inf / nan) goes through strtod.
+  static const double p10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16,
+                                 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+  if (!text || !out || max_lines < 0 || max_out < 0) return -1;
+  const char *p = text, *end = text + len;
+  int64_t count = 0, lines = 0, cols0 = -1;
+  while (p < end && lines < max_lines) {
+    int64_t cols = 0;
+    for (;;) {  // one line
+      while (p < end && (*p == ' ' || *p == '\t' || *p == '\r')) ++p;
+      if (p >= end || *p == '\n') break;
+      const char *tok = p;
+      bool neg = false;
+      if (*p == '-' || *p == '+') { neg = *p == '-'; ++p; }
+      uint64_t mant = 0;
+      int nd = 0, e10 = 0;
+      bool digits = false, fast = true;
+      while (p < end && *p >= '0' && *p <= '9') {
+        digits = true;
+        if (nd < 19) { mant = mant * 10 + (uint64_t)(*p - '0'); if (mant) ++nd; } else fast = false;
+        ++p;
+      }
+      if (p < end && *p == '.') {
+        ++p;
+        while (p < end && *p >= '0' && *p <= '9') {
+          digits = true;
+          if (nd < 19) { mant = mant * 10 + (uint64_t)(*p - '0'); if (mant) ++nd; --e10; } else fast = false;  // further digits: below 1 ulp of 19 digits, but be exact
+          ++p;
+        }
+      }
+      if (digits && p < end && (*p == 'e' || *p == 'E')) {
+        const char *q = p + 1;
+        bool eneg = false;
+        if (q < end && (*q == '-' || *q == '+')) { eneg = *q == '-'; ++q; }
+        if (q < end && *q >= '0' && *q <= '9') {
+          int ev = 0;
+          while (q < end && *q >= '0' && *q <= '9') { if (ev < 10000) ev = ev * 10 + (*q - '0'); ++q; }
+          e10 += eneg ? -ev : ev;
+          p = q;
+        }
+      }
+      const bool ends = p >= end || *p == ' ' || *p == '\t' || *p == '\r' || *p == '\n';
+      double v;
+      if (digits && ends && fast && mant < (1ull << 53) && e10 >= -22 && e10 <= 22) {
+        v = (double)mant;
+        v = e10 < 0 ? v / p10[-e10] : v * p10[e10];
+        if (neg) v = -v;
+      } else {  // slow path: let strtod decide (also rejects garbage)
+        const char *t = tok;
+        while (t < end && !(*t == ' ' || *t == '\t' || *t == '\r' || *t == '\n')) ++t;
+        std::string buf(tok, t);
+        char *stop = nullptr;
+        v = strtod(buf.c_str(), &stop);
+        if (buf.empty() || stop != buf.c_str() + buf.size()) return -1;
+        p = t;
+      }
+      if (count >= max_out) return -1;
+      out[count++] = v;
+      ++cols;
+    }
+    if (p < end && *p == '\n') ++p;
+    if (cols == 0) continue;  // blank line
+    if (cols0 < 0) cols0 = cols;
+    else if (cols != cols0) return -1;
+    ++lines;
+  }
+  if (n_lines) *n_lines = lines;
+  if (n_cols) *n_cols = cols0 < 0 ? 0 : cols0;
+  return count;
+}
+
 int gmr_bvh_fk(const int32_t *parents, int n_joints, const int32_t *euler_order, const int32_t *extra_pos_src,
                const int32_t *extra_rot_src, int n_extra, const double *local_pos, const double *euler_rad, int64_t n_frames,
                double scale, double *pos_out, double *quat_out, void *stream) {

@@ -31,6 +31,8 @@
  *                      (scripts/smplx_to_robot_dataset.py:118-126)
  *   gmr_smplx_keypoints the numeric part of get_smplx_data_offline_fast (general_motion_retargeting/utils/smpl.py:109-198)
  *                      after the SMPL-X body model: slerp/lerp to the target frame rate, orientation chaining
+ *   gmr_bvh_parse_motion the MOTION block of read_bvh (general_motion_retargeting/utils/lafan_vendor/extract.py:140-166): the
+ *                      per-line regex + float() loop that dominates BVH loading in the reference
  *   gmr_bvh_fk         the numeric part of load_lafan1_file (general_motion_retargeting/utils/lafan1.py:8-40):
  *                      euler_to_quat + quat_fk (utils/lafan_vendor/utils.py:56-103), Y-up -> Z-up, cm -> m,
  *                      LeftFootMod / RightFootMod synthesis
@@ -149,6 +151,13 @@ int gmr_fk_min_height(gmr_model *m, const float *root_pos, const float *root_rot
 int gmr_smplx_keypoints(const int32_t *parents, int n_joints, int joints_stride, const double *global_orient, const double *full_pose,
                         const double *joints, int64_t n_frames, int64_t n_frames_out, int resample, double *pos_out, double *quat_out,
                         void *stream);
+
+/* Host-side text parse of a BVH MOTION block (stateless, no device involved): the first max_lines non-empty lines of
+ * text[0..len) are read as whitespace-separated decimal numbers into out (host, capacity max_out doubles), correctly
+ * rounded like Python's float().  *n_lines = lines read, *n_cols = numbers on the first line.  Returns the count of numbers
+ * written, or -1 on a malformed token, a line whose length differs from the first, or an overflow of max_out.            */
+int64_t gmr_bvh_parse_motion(const char *text, size_t len, int64_t max_lines, double *out, int64_t max_out, int64_t *n_lines,
+                             int64_t *n_cols);
 
 /* BVH skeleton FK (stateless).  Joints in hierarchy order (parents[0] = -1, parents[j] < j), one Euler triple per joint.
  *   parents, euler_order[3] (0=x,1=y,2=z, the order the channels are listed), extra_*_src[n_extra]: host

@@ -187,3 +187,32 @@ def test_bvh_parser_follows_reference_file_semantics(golden_dir, tmp_path):
     bad.write_text("HIERARCHY\nROOT a\n{\nOFFSET 0 0 0\nCHANNELS 6 Xposition Yposition Zposition Zrotation Yrotation Xrotation\n}\nMOTION\nFrames: 2\nFrame Time: 0.03\n0 0 0 0 0 0\n")
     with pytest.raises(ValueError):
         read_bvh(str(bad))
+
+
+def test_bvh_motion_parser_matches_python_float():
+    """gmr_bvh_parse_motion (host code of libgmr_amd.so): every token is the double Python's float() gives -- the reference's
+    read_bvh does float() per regex group (utils/lafan_vendor/extract.py:140-166) -- including the cases outside the fast path."""
+    import ctypes as C
+    from gmr_amd import _native
+    lib = _native.load()
+    rng = np.random.default_rng(0)
+    vals = np.concatenate([rng.normal(size=400) * 10.0 ** rng.integers(-8, 9, size=400), [0.0, -0.0, 1e22, 1e23, 5e-324, 1.7976931348623157e308]])
+    toks = []
+    for k, v in enumerate(vals):
+        toks.append([repr(float(v)), f"{v:.6f}", f"{v:.17g}", f"{v:+.3e}"][k % 4])
+    toks += ["123456789012345678901234567890", ".5", "-5.", "1E+5", "9007199254740993", "0.1", "1e400", "-1e400", "nan", "007.250"]
+    ncol = 8
+    toks = toks[: len(toks) // ncol * ncol]
+    lines = [" ".join(toks[i:i + ncol]) for i in range(0, len(toks), ncol)]
+    text = ("\n\n" + "\r\n".join(lines[:10]) + "\n  \t\n" + "\n".join(lines[10:]) + "\n").encode()
+    out = np.empty(len(toks) + 4)
+    nl, nc = C.c_int64(), C.c_int64()
+    n = lib.gmr_bvh_parse_motion(text, len(text), len(lines), out.ctypes.data, len(out), C.byref(nl), C.byref(nc))
+    assert n == len(toks) and nl.value == len(lines) and nc.value == ncol
+    exp = np.array([float(t) for t in toks])
+    assert np.array_equal(out[:n], exp, equal_nan=True) and np.array_equal(np.signbit(out[:n]), np.signbit(exp))
+    # max_lines stops early; ragged rows, garbage and overflow are errors
+    assert lib.gmr_bvh_parse_motion(text, len(text), 3, out.ctypes.data, len(out), C.byref(nl), C.byref(nc)) == 3 * ncol and nl.value == 3
+    for bad in (b"1 2 3\n4 5\n", b"1 2x 3\n", b"1 - 3\n", b"1 2 3 4 5 6 7 8 9\n" * 2):
+        cap = 8 if bad.startswith(b"1 2 3 4") else len(out)
+        assert lib.gmr_bvh_parse_motion(bad, len(bad), 10, out.ctypes.data, cap, C.byref(nl), C.byref(nc)) == -1
