@@ -70,7 +70,12 @@ typedef unsigned long long u64;
 #define GMR_IK_WAVES_PER_SIMD 2
 #endif
 
-constexpr int kBT = 27;  // doubles per task block: LL(6) LA(9) AA(6) g(6)
+constexpr int kBT = 27;  // doubles per task block: LL(6) LA(9) AA(6) g(6), stored "by column": element 3k + s with s = 0..2 and
+// k: 0 LL(s,s)  1 LL(s,s+1)  2..4 LA(s,s), LA(s,s+1), LA(s,s+2)  5 AA(s,s)  6 AA(s,s+1)  7 gl_s  8 ga_s   (indices mod 3)
+// -- the order in which three lanes per task (one per column s) produce it in task_block_quad
+__host__ __device__ constexpr int bt_ll(int i, int j) { return i == j ? i : ((j - i + 3) % 3 == 1 ? 3 + i : 3 + j); }
+__host__ __device__ constexpr int bt_la(int i, int j) { return 3 * (2 + (j - i + 3) % 3) + i; }
+__host__ __device__ constexpr int bt_aa(int i, int j) { return i == j ? 15 + i : ((j - i + 3) % 3 == 1 ? 18 + i : 18 + j); }
 constexpr int kMaxCompPass = 32;  // passes of the composite plan (two composites per pass, children before parents)
 constexpr double kLieEps = 1e-10;  // mink.lie.utils.get_epsilon(float64)
 
@@ -478,22 +483,20 @@ __device__ __forceinline__ double task_block(int body, const double *xpos, const
     V[3 * i + 2] -= a * xb[1] - b * xb[0];
   }
   const double wp2 = wp * wp, wr2 = wr * wr;
-  // symmetric 3x3 products, index order xx xy xz yy yz zz
-  int n = 0;
+  // symmetric 3x3 products
 #pragma unroll
   for (int i = 0; i < 3; i++)
 #pragma unroll
     for (int j = i; j < 3; j++) {
       const double uu = U[i] * U[j] + U[3 + i] * U[3 + j] + U[6 + i] * U[6 + j];
       const double vv = V[i] * V[j] + V[3 + i] * V[3 + j] + V[6 + i] * V[6 + j];
-      out[n] = wp2 * uu;
-      out[15 + n] = wp2 * vv + wr2 * uu;
-      n++;
+      out[bt_ll(i, j)] = wp2 * uu;
+      out[bt_aa(i, j)] = wp2 * vv + wr2 * uu;
     }
 #pragma unroll
   for (int i = 0; i < 3; i++)
 #pragma unroll
-    for (int j = 0; j < 3; j++) out[6 + 3 * i + j] = wp2 * (U[i] * V[j] + U[3 + i] * V[3 + j] + U[6 + i] * V[6 + j]);
+    for (int j = 0; j < 3; j++) out[bt_la(i, j)] = wp2 * (U[i] * V[j] + U[3 + i] * V[3 + j] + U[6 + i] * V[6 + j]);
   // g = A_t' W^2 e = -[U'(wp2 e_v) ; V'(wp2 e_v) + U'(wr2 e_w)]
   const double ev[3] = {wp2 * e[0], wp2 * e[1], wp2 * e[2]}, ew[3] = {wr2 * e[3], wr2 * e[4], wr2 * e[5]};
 #pragma unroll
@@ -504,15 +507,99 @@ __device__ __forceinline__ double task_block(int body, const double *xpos, const
   return wp2 * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) + wr2 * th2;
 }
 
-// y = B [m; a] for a 6x6 symmetric block stored as LL(6) LA(9) AA(6)
+// y = B [m; a] for a 6x6 symmetric block [[LL, LA],[LA', AA]] in the layout of kBT
 __device__ __forceinline__ void sym6_mul(const double *B, const double m[3], const double a[3], double fl[3], double fa[3]) {
-  const double *LL = B, *LA = B + 6, *AA = B + 15;
-  fl[0] = LL[0] * m[0] + LL[1] * m[1] + LL[2] * m[2] + LA[0] * a[0] + LA[1] * a[1] + LA[2] * a[2];
-  fl[1] = LL[1] * m[0] + LL[3] * m[1] + LL[4] * m[2] + LA[3] * a[0] + LA[4] * a[1] + LA[5] * a[2];
-  fl[2] = LL[2] * m[0] + LL[4] * m[1] + LL[5] * m[2] + LA[6] * a[0] + LA[7] * a[1] + LA[8] * a[2];
-  fa[0] = LA[0] * m[0] + LA[3] * m[1] + LA[6] * m[2] + AA[0] * a[0] + AA[1] * a[1] + AA[2] * a[2];
-  fa[1] = LA[1] * m[0] + LA[4] * m[1] + LA[7] * m[2] + AA[1] * a[0] + AA[3] * a[1] + AA[4] * a[2];
-  fa[2] = LA[2] * m[0] + LA[5] * m[1] + LA[8] * m[2] + AA[2] * a[0] + AA[4] * a[1] + AA[5] * a[2];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    fl[i] = B[bt_ll(i, 0)] * m[0] + B[bt_ll(i, 1)] * m[1] + B[bt_ll(i, 2)] * m[2] + B[bt_la(i, 0)] * a[0] + B[bt_la(i, 1)] * a[1] + B[bt_la(i, 2)] * a[2];
+    fa[i] = B[bt_la(0, i)] * m[0] + B[bt_la(1, i)] * m[1] + B[bt_la(2, i)] * m[2] + B[bt_aa(i, 0)] * a[0] + B[bt_aa(i, 1)] * a[1] + B[bt_aa(i, 2)] * a[2];
+  }
+}
+
+// ------------------------------------------------------------------ task block on three lanes per task
+// Same block as task_block, produced by lanes 4t + s, s = 0..2 (lane 4t + 3 idles): the part that depends on the error only
+// (A, Bo) is computed by all three, then lane s builds column s of U = A R' and of V = (Bo - A [R'x]x) R' (R'[x]x = [R'x]x R'
+// for a rotation, which removes the cross-column term), fetches the two other columns from its quad neighbours with DPP
+// quad_perm, and forms the 9 products that make element 3k + s of the block.  ~250 instructions instead of ~460.
+template <int CTRL>
+__device__ __forceinline__ double quad_get(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double pick3(double a, double b, double c, int s) { return s == 0 ? a : (s == 1 ? b : c); }
+__device__ __forceinline__ double task_block_quad(int body, int s, const double *xpos, const double *xquat, const double e[6], double sh,
+                                                  double ch, double wp, double wr, double *out) {
+  const double *u = e, *ph = e + 3;
+  const double th2 = ph[0] * ph[0] + ph[1] * ph[1] + ph[2] * ph[2];
+  const double pu = ph[0] * u[0] + ph[1] * u[1] + ph[2] * u[2];
+  double kap = 0, bet = 0;
+  const bool small = th2 < kLieEps;  // mink SE3.ljacinv returns the identity below this threshold
+  if (!small) {
+    const double th = fast_sqrt(th2), ith2 = fast_rcp(th2);
+    const double is = fast_rcp(sh), cot = ch * is;
+    kap = (1.0 - 0.5 * th * cot) * ith2;
+    const double delta = 0.25 * th * is * is - 0.5 * cot;
+    bet = (kap - 0.5 * delta * fast_rcp(th)) * ith2;
+  }
+  double A[9], Bo[9];
+  const double k2 = -2.0 * bet * pu;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const double pp = ph[i] * ph[j] - (i == j ? th2 : 0.0);
+      A[3 * i + j] = (i == j ? 1.0 : 0.0) + kap * pp;
+      Bo[3 * i + j] = small ? 0.0 : kap * (ph[i] * u[j] + u[i] * ph[j] - (i == j ? 2.0 * pu : 0.0)) + k2 * pp;
+    }
+  if (!small) {
+    A[1] += 0.5 * ph[2]; A[2] -= 0.5 * ph[1]; A[3] -= 0.5 * ph[2]; A[5] += 0.5 * ph[0]; A[6] += 0.5 * ph[1]; A[7] -= 0.5 * ph[0];
+    Bo[1] += 0.5 * u[2]; Bo[2] -= 0.5 * u[1]; Bo[3] -= 0.5 * u[2]; Bo[5] += 0.5 * u[0]; Bo[6] += 0.5 * u[1]; Bo[7] -= 0.5 * u[0];
+  }
+  const double qb[4] = {xquat[4 * body], xquat[4 * body + 1], xquat[4 * body + 2], xquat[4 * body + 3]};
+  const double xw[3] = {xpos[3 * body], xpos[3 * body + 1], xpos[3 * body + 2]};
+  double R[9], xb[3];
+  q2mat(qb, R);
+  mtv(R, xw, xb);  // body-frame position of the body origin
+  // M = Bo - A [xb]x
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const double a0 = A[3 * i], a1 = A[3 * i + 1], a2 = A[3 * i + 2];
+    Bo[3 * i] -= a1 * xb[2] - a2 * xb[1];
+    Bo[3 * i + 1] -= a2 * xb[0] - a0 * xb[2];
+    Bo[3 * i + 2] -= a0 * xb[1] - a1 * xb[0];
+  }
+  // column s of (. R') = (.) times row s of R
+  const double r0 = pick3(R[0], R[3], R[6], s), r1 = pick3(R[1], R[4], R[7], s), r2 = pick3(R[2], R[5], R[8], s);
+  double uc[3], vc[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    uc[i] = A[3 * i] * r0 + A[3 * i + 1] * r1 + A[3 * i + 2] * r2;
+    vc[i] = Bo[3 * i] * r0 + Bo[3 * i + 1] * r1 + Bo[3 * i + 2] * r2;
+  }
+  // columns s+1 and s+2 from the quad neighbours (quad_perm [1,2,0,3] = 0xC9 and [2,0,1,3] = 0xD2)
+  double u1[3], v1[3], u2[3], v2[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    u1[i] = quad_get<0xC9>(uc[i]); v1[i] = quad_get<0xC9>(vc[i]);
+    u2[i] = quad_get<0xD2>(uc[i]); v2[i] = quad_get<0xD2>(vc[i]);
+  }
+  const double wp2 = wp * wp, wr2 = wr * wr;
+  auto dot = [](const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+  const double uu = dot(uc, uc), uu1 = dot(uc, u1);
+  const double ev[3] = {wp2 * e[0], wp2 * e[1], wp2 * e[2]}, ew[3] = {wr2 * e[3], wr2 * e[4], wr2 * e[5]};
+  if (s < 3) {
+    out[s] = wp2 * uu;                                   // LL(s,s)
+    out[3 + s] = wp2 * uu1;                              // LL(s,s+1)
+    out[6 + s] = wp2 * dot(uc, vc);                      // LA(s,s)
+    out[9 + s] = wp2 * dot(uc, v1);                      // LA(s,s+1)
+    out[12 + s] = wp2 * dot(uc, v2);                     // LA(s,s+2)
+    out[15 + s] = wp2 * dot(vc, vc) + wr2 * uu;          // AA(s,s)
+    out[18 + s] = wp2 * dot(vc, v1) + wr2 * uu1;         // AA(s,s+1)
+    out[21 + s] = -dot(uc, ev);                          // g = A_t' W^2 e = -[U'(wp2 e_v) ; V'(wp2 e_v) + U'(wr2 e_w)]
+    out[24 + s] = -(dot(vc, ev) + dot(uc, ew));
+  }
+  return wp2 * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) + wr2 * th2;
 }
 
 // ------------------------------------------------------------------ exact box QP, lane = dof (row of H)
@@ -974,8 +1061,11 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
     for (int tab = 0; tab < 2; ++tab) {
       if (!m.use_table[tab]) continue;
       const int nt = m.ntask[tab];
-      const bool is_task = lane < nt;
-      const int trow = tab * GMR_MAX_TASKS + (is_task ? lane : 0);
+      // task lanes: up to 16 tasks get a quad each (lanes 4t .. 4t+2 share the task block, task_block_quad); more than 16 one lane
+      const bool quad = nt <= 16;
+      const int tl = quad ? lane >> 2 : lane, ts = quad ? lane & 3 : 0;
+      const bool is_task = tl < nt, counts = is_task && ts == 0;  // counts: the one lane of a task that enters wave sums
+      const int trow = tab * GMR_MAX_TASKS + (is_task ? tl : 0);
       const int t_body = m.tbody[trow], t_slot = m.tslot[trow];
       const double t_wp = m.twp[trow], t_wr = m.twr[trow];
       const int a_comp = m.acomp[tab * 64 + arow];
@@ -987,15 +1077,19 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
       if (!poses_valid) fk_phase<GMR_IK_STAGE_TREE != 0>(m, bodyc, nbody, fkrounds, lane, q, xpos, xquat);
       poses_valid = true;
       GMR_STAMP(1);
-      double curr = fast_sqrt(wave_sum(is_task ? task_residual(t_body, t_slot, xpos, xquat, tp, tq, e, sh, ch) : 0.0));
+      double r2 = is_task ? task_residual(t_body, t_slot, xpos, xquat, tp, tq, e, sh, ch) : 0.0;
+      double curr = fast_sqrt(wave_sum(counts ? r2 : 0.0));
       GMR_STAMP(2);
       int num_iter = 0;
       bool first = true;
       for (;;) {
         // ---- per-task 6x6 blocks ----
         double mu = 0.0;
-        GMR_DUP(3) if (is_task) mu = task_block(t_body, xpos, xquat, e, sh, ch, t_wp, t_wr, Bt + kBT * lane);
-        const double diag = prm.damping + prm.lm_damping * wave_sum(mu);
+        GMR_DUP(3) if (is_task) {
+          if (quad) mu = task_block_quad(t_body, ts, xpos, xquat, e, sh, ch, t_wp, t_wr, Bt + kBT * tl);
+          else mu = task_block(t_body, xpos, xquat, e, sh, ch, t_wp, t_wr, Bt + kBT * tl);
+        }
+        const double diag = prm.damping + prm.lm_damping * wave_sum(counts ? mu : 0.0);
         GMR_STAMP(3);
         // ---- screws S_i (world frame, about the origin) ----
         double Si[6] = {0, 0, 0, 0, 0, 0};
@@ -1161,7 +1255,10 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         GMR_DUP(1) fk_phase<GMR_IK_STAGE_TREE != 0>(m, bodyc, nbody, fkrounds, lane, q, xpos, xquat);
         GMR_STAMP(1);
         double next = 0.0;
-        GMR_DUP(2) next = fast_sqrt(wave_sum(is_task ? task_residual(t_body, t_slot, xpos, xquat, tp, tq, e, sh, ch) : 0.0));
+        GMR_DUP(2) {
+          r2 = is_task ? task_residual(t_body, t_slot, xpos, xquat, tp, tq, e, sh, ch) : 0.0;
+          next = fast_sqrt(wave_sum(counts ? r2 : 0.0));
+        }
         GMR_STAMP(2);
         if (!first) ++num_iter;
         first = false;
