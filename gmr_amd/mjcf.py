@@ -23,7 +23,6 @@ from __future__ import annotations
 
 import dataclasses
 import json
-import math
 import os
 import xml.etree.ElementTree as ET
 from typing import Dict, List, Optional

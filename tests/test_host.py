@@ -9,7 +9,7 @@ import pytest
 from gmr_amd import params
 from gmr_amd.ik_config import load_ik_config
 from gmr_amd.mjcf import MjcfError, load_mjcf, load_robot
-from gmr_amd.model import HEADER_BYTES, compile_model
+from gmr_amd.model import HEADER_BYTES
 from gmr_amd.schedule import make_items, partition_clips
 from tests.util import CONFIG_ROBOTS, compiled
 

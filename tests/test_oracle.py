@@ -14,7 +14,7 @@ import pytest
 from scipy.optimize import lsq_linear
 
 from gmr_amd import synth
-from oracle.oracle import IKParams, Oracle, WORK_ITEM_DTYPE, box_qp
+from oracle.oracle import Oracle, WORK_ITEM_DTYPE, box_qp
 from tests.util import CONFIG_ROBOTS, compiled, make_items, quat_angle
 
 GOLDEN_ROBOTS = ["unitree_g1", "unitree_g1_with_hands", "booster_t1", "stanford_toddy", "fourier_n1"]

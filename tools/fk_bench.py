@@ -1,5 +1,5 @@
 """Throughput of the KinematicsModel FK kernels (gmr_fk / gmr_fk_min_height) against the HBM roofline."""
-import sys, os, time, json
+import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from gmr_amd import params
