@@ -884,7 +884,9 @@ int gmr_fk(gmr_model *m, const float *root_pos, const float *root_rot_xyzw, cons
   HIP_TRY(m, hipSetDevice(m->device));
   const int64_t nblk = (n_frames + gmr::kFkThreads - 1) / gmr::kFkThreads;
   if (nblk > 0x7fffffff) { set_err(m, "too many frames for one launch"); return GMR_EINVAL; }
-  hipLaunchKernelGGL((gmr::fk_kernel<0>), dim3((unsigned)nblk), dim3(gmr::kFkThreads), m->fk_lds_bytes, static_cast<hipStream_t>(stream), m->fk,
+  // the rotation stage is the last LDS region: a positions-only call does not allocate it (more workgroups per CU)
+  const int fk_lds = body_rot_out ? m->fk_lds_bytes : m->fk_lds_bytes - gmr::kFkRotStride * gmr::kFkThreads * (int)sizeof(float);
+  hipLaunchKernelGGL((gmr::fk_kernel<0>), dim3((unsigned)nblk), dim3(gmr::kFkThreads), fk_lds, static_cast<hipStream_t>(stream), m->fk,
                      root_pos, root_rot_xyzw, dof, n_frames, body_pos_out, body_rot_out, (const int64_t *)nullptr, 0, (int *)nullptr);
   HIP_TRY(m, hipGetLastError());
   return GMR_OK;

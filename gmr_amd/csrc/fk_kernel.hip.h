@@ -25,7 +25,10 @@
 namespace gmr {
 
 constexpr int kFkThreads = 128;
-constexpr int kFkGroup = 4;                        // bodies per output flush
+#ifndef GMR_FK_GROUP
+#define GMR_FK_GROUP 8
+#endif
+constexpr int kFkGroup = GMR_FK_GROUP;             // bodies per output flush
 constexpr int kFkPosStride = 3 * kFkGroup + 1;    // LDS words per lane of the position stage (odd: conflict-free)
 constexpr int kFkRotStride = 4 * kFkGroup + 1;
 constexpr int kFkMaxSlots = 12;
