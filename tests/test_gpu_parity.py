@@ -51,9 +51,13 @@ def test_fk_golden(robot, golden_dir, dev):
 
 @pytest.mark.parametrize("robot", CONFIG_ROBOTS)
 @pytest.mark.parametrize("hard", [False, True])
-def test_ik_matches_oracle(robot, hard, dev):
+@pytest.mark.parametrize("qp", ["structured", "generic"])
+def test_ik_matches_oracle(robot, hard, qp, dev, monkeypatch):
+    """Both linear-algebra back ends of the box QP against the oracle; GMR_AMD_GENERIC_QP is read at model creation."""
+    monkeypatch.setenv("GMR_AMD_GENERIC_QP", "1" if qp == "generic" else "0")
     cm = compiled("smplx", robot)
     eng, orc = _engine(cm), Oracle(cm.blob)
+    assert (eng.info.reserved[0] == 0) == (qp == "generic")  # core size of the structured layout, 0 = dense generic QP
     pos, quat, names, offs, _ = synth.synth_clips(cm, 3, 40, seed=21, hard=hard, dtype=np.float32)
     sc = cm.slot_columns(names)
     items = make_items(offs)
