@@ -380,7 +380,8 @@ int build_device_model(gmr_model *m) {
     }
     if (ncomp[k] > 2 * GMR_MAX_TASKS) { set_err(m, "too many composite nodes"); return GMR_EUNSUPPORTED; }
     // renumber the composites so that a composite's children (maximal strict subsets) always have lower ids, and split
-    // each into "own tasks" + "child composites": Bc[c] = sum_{t in own} Bt[t] + sum_{d in kids} Bc[d]
+    // each into "own tasks" + "child composites": Bc[c] = sum_{t in own} Bt[t] + sum_{d in kids} Bc[d]  (any number of either:
+    // the pass plan below splits a long sum into entries of four sources)
     const int nc = ncomp[k];
     if (nc > 32) { set_err(m, "more than 32 composite nodes"); return GMR_EUNSUPPORTED; }
     std::vector<int> order(nc), newid(nc);
@@ -399,7 +400,6 @@ int build_device_model(gmr_model *m) {
         kids |= 1u << d; covered |= md;
       }
       own &= ~covered;
-      if (__builtin_popcount(own) > 4 || __builtin_popcount(kids) > 4) { set_err(m, "composite %d of table %d: more than 4 own tasks / children", o, k + 1); return GMR_EUNSUPPORTED; }
       comp_own[k * 32 + o] = own; comp_kids[k * 32 + o] = kids;
     }
   }

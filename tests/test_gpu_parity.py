@@ -68,3 +68,16 @@ def test_ik_matches_oracle(robot, hard, qp, dev, monkeypatch):
     assert (it >> 30).max() == 0, "a QP hit its iteration cap"
     assert _qpos_diff(q, q_ref) < 1e-6, _qpos_diff(q, q_ref)
     assert np.array_equal(it, it_ref)
+
+
+@pytest.mark.parametrize("robot", ["kuavo_s45", "hightorque_hi", "booster_k1"])
+def test_ik_matches_oracle_other_registry_robots(robot, dev):
+    """The registry's remaining humanoids with an IK config (13 / 15 / 12 tasks; booster_k1 has a composite that sums more than
+    four child blocks, split over two plan entries)."""
+    cm = compiled("smplx", robot)
+    eng, orc = _engine(cm), Oracle(cm.blob)
+    pos, quat, names, offs, _ = synth.synth_clips(cm, 2, 30, seed=3, hard=True, dtype=np.float32, amp=0.2)
+    sc = cm.slot_columns(names)
+    q_ref, it_ref, _ = orc.ik_solve(pos, quat, sc, make_items(offs))
+    q, it, _ = eng.ik_solve(torch.from_numpy(pos).to(dev), torch.from_numpy(quat).to(dev), sc, make_items(offs))
+    assert _qpos_diff(q.cpu().numpy(), q_ref) < 1e-6 and np.array_equal(it.cpu().numpy(), it_ref)
