@@ -81,3 +81,48 @@ def test_ik_matches_oracle_other_registry_robots(robot, dev):
     q_ref, it_ref, _ = orc.ik_solve(pos, quat, sc, make_items(offs))
     q, it, _ = eng.ik_solve(torch.from_numpy(pos).to(dev), torch.from_numpy(quat).to(dev), sc, make_items(offs))
     assert _qpos_diff(q.cpu().numpy(), q_ref) < 1e-6 and np.array_equal(it.cpu().numpy(), it_ref)
+
+
+def _synthetic_robot(tmp_path, limbs, with_tasks_per_limb):
+    """A floating base with `limbs` chains of hinges (list of chain lengths) hanging off it; tasks on the base and on every
+    `with_tasks_per_limb`-th link of each chain.  Returns a compiled model."""
+    from gmr_amd.ik_config import IKConfig, IKTask
+    from gmr_amd.mjcf import load_mjcf
+    from gmr_amd.model import compile_model
+    axes = ["1 0 0", "0 1 0", "0 0 1"]
+    xml = ['<mujoco model="synth"><compiler angle="radian"/><worldbody><body name="base" pos="0 0 1"><freejoint/>']
+    tasks = [("base", "h_base")]
+    for li, n in enumerate(limbs):
+        ang = 2 * np.pi * li / len(limbs)
+        for k in range(n):
+            pos = f"{0.15 * np.cos(ang):.4f} {0.15 * np.sin(ang):.4f} 0" if k == 0 else "0.02 0.01 -0.12"
+            xml.append(f'<body name="l{li}_{k}" pos="{pos}"><joint name="j{li}_{k}" axis="{axes[(k + li) % 3]}" range="-1.2 1.4"/>')
+            if (k + 1) % with_tasks_per_limb == 0 or k == n - 1:
+                tasks.append((f"l{li}_{k}", f"h{li}_{k}"))
+        xml.append("</body>" * n)
+    xml.append("</body></worldbody></mujoco>")
+    p = tmp_path / "synth.xml"
+    p.write_text("".join(xml))
+    robot = load_mjcf(str(p))
+    t1 = [IKTask(f, h, 0.0 if i % 3 else 50.0, 10.0, [0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0]) for i, (f, h) in enumerate(tasks)]
+    t2 = [IKTask(f, h, 10.0, 5.0, [0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0]) for f, h in tasks]
+    cfg = IKConfig("base", "h_base", 0.0, 1.8, True, True, {h: 1.0 for _, h in tasks}, t1, t2, source="synthetic")
+    return compile_model(robot, cfg)
+
+
+@pytest.mark.parametrize("limbs,every,expect_nvp,expect_struct", [
+    ([9, 9, 8, 8], 3, 40, True),          # 40 dofs: four limbs of <= 9 behind a 6-dof core -> structured, NVP 40
+    ([7, 7, 7, 7, 7, 7], 2, 48, False),   # 48 dofs, six limbs: more than four bins -> dense generic QP, NVP 48; 19 tasks (> 16: one lane per task)
+    ([14, 14, 14, 14], 4, 64, False),     # 62 dofs: limbs too long for a 16-wide group -> generic, NVP 64, deepest tree
+])
+def test_synthetic_large_robots(limbs, every, expect_nvp, expect_struct, dev, tmp_path):
+    """Kernel variants the registry robots never reach (NVP 40 / 48 / 64, dense QP on big systems, > 16 tasks), against the oracle."""
+    cm = _synthetic_robot(tmp_path, limbs, every)
+    eng, orc = _engine(cm), Oracle(cm.blob)
+    assert eng.info.nv_padded == expect_nvp and (eng.info.reserved[0] > 0) == expect_struct, (eng.info.nv_padded, eng.info.reserved[0])
+    pos, quat, names, offs, _ = synth.synth_clips(cm, 2, 16, seed=4, hard=True, dtype=np.float64, amp=0.2)
+    sc = cm.slot_columns(names)
+    q_ref, it_ref, _ = orc.ik_solve(pos, quat, sc, make_items(offs))
+    q, it, _ = eng.ik_solve(torch.from_numpy(pos).to(dev), torch.from_numpy(quat).to(dev), sc, make_items(offs))
+    assert (it.cpu().numpy() >> 30).max() == 0
+    assert _qpos_diff(q.cpu().numpy(), q_ref) < 1e-6 and np.array_equal(it.cpu().numpy(), it_ref)
