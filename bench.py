@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--clips", type=int, default=2048, help="clips per GPU")
+    ap.add_argument("--clips", type=int, default=8192, help="clips per GPU (AMASS holds >1e4 sequences; several clips per wavefront slot -- 2048 slots on a MI355X -- let the hardware dispatcher balance clips that need more solves than others)")
     ap.add_argument("--frames", type=int, default=3000, help="frames per clip (one AMASS sequence ~3k frames @30fps)")
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic clips generated, tiled to --clips")
     ap.add_argument("--cpu-clips", type=int, default=0, help="clips solved by the CPU oracle (baseline + parity); 0 = 2 per host core, capped at 512")
