@@ -480,3 +480,14 @@ def test_verification_walk_matches_oracle():
     with pytest.raises(Exception):
         bad = walks.copy(); bad["n_burn"] = 1
         eng.ik_solve(tp, tq, sc, bad, qpos_init=qf_g, qpos_final=qf_g)
+
+
+def test_error1_equals_error2_for_same_map_tables():
+    """fbx_to_g1.json maps the same frames in both tables: error1() == error2() after every retarget, the identity the reference's
+    own error logs show on all 2 031 rows (tests/golden/ref_fixtures)."""
+    from gmr_amd import GeneralMotionRetargeting as GMR
+    g = GMR("fbx", "unitree_g1")
+    pos, quat, names, offs, _ = synth.synth_clips(g._cm, 1, 5, seed=2, hard=True, dtype=np.float64)
+    for f in range(5):
+        g.retarget(_frames(pos, quat, names, f))
+        assert g.error1() == g.error2() and g.error1() > 0

@@ -253,3 +253,29 @@ def test_offset_to_ground_and_height_ratio():
     tp0, _ = orc.prepare_targets(hp, hq)
     rs = cm.root_slot
     assert np.allclose(tp0[rs] - synth.qrot(tq[rs], cm.slot_pos_off[rs]), cm.slot_scale[rs] * hp[rs])
+
+
+def test_reference_error_logs_error1_equals_error2(golden_dir):
+    """The only IK-side numbers the reference ships: per-frame error logs of scripts/fbx_to_robot.py:983-1060 (errors.csv,
+    test_errors.csv, copied as data to tests/golden/ref_fixtures).  fbx_to_g1.json maps the same frames in both tables, so
+    error1 == error2 on every logged row; the restatement must reproduce that identity (SURVEY 8(c), weak pin (i))."""
+    import csv
+    rows = 0
+    for name in ("errors.csv", "test_errors.csv"):
+        with open(os.path.join(golden_dir, "ref_fixtures", name)) as f:
+            for r in csv.DictReader(f):
+                assert r["error1"] == r["error2"]
+                rows += 1
+    assert rows == 2031
+    cm = compiled("fbx", "unitree_g1")
+    assert [t.frame for t in cm.tasks[0]] == [t.frame for t in cm.tasks[1]]
+    orc = Oracle(cm.blob)
+    pos, quat, names, offs, _ = synth.synth_clips(cm, 1, 6, seed=2, hard=True, dtype=np.float64)
+    sc = cm.slot_columns(names)
+    q = np.array(cm.robot.qpos0, dtype=np.float64)
+    for f in range(6):
+        q, _, errs = orc.retarget_frame(q, pos[f][sc], quat[f][sc])
+        tp, tq = orc.prepare_targets(pos[f][sc], quat[f][sc])
+        e1, _ = orc.stage_error(0, q, tp, tq, len(cm.tasks[0]))
+        e2, _ = orc.stage_error(1, q, tp, tq, len(cm.tasks[1]))
+        assert e1 == e2 and e1 > 0
