@@ -213,6 +213,12 @@ class GeneralMotionRetargeting:
         Returns qpos ``[N, nq]`` float64 (same container kind as the input) and, optionally, solves per frame.
         """
         is_np = isinstance(pos, np.ndarray)
+        cols = self._columns(list(body_names))  # KeyError where the reference raises
+        if is_np and isinstance(quat, np.ndarray) and pos.ndim == 3 and pos.shape[1] > len(cols):
+            # host arrays with more bodies than the config consumes (55 SMPL-X joints, 14 used): gather the used columns on the
+            # host first -- a quarter of the bytes cross PCIe
+            pos, quat = pos[:, cols], quat[:, cols]
+            cols = np.arange(len(cols), dtype=np.int32)
         tpos = torch.from_numpy(np.ascontiguousarray(pos)) if is_np else pos
         tquat = torch.from_numpy(np.ascontiguousarray(quat)) if isinstance(quat, np.ndarray) else quat
         tpos, tquat = tpos.to(self.device), tquat.to(self.device)
@@ -224,10 +230,10 @@ class GeneralMotionRetargeting:
             raise ValueError("seq_offsets must span [0, N]")
         if chunk > 0 and verify:
             out, iters, self.last_chunk_info = self._engine.ik_solve_chunked(
-                tpos, tquat, self._columns(list(body_names)), offs, chunk, burn_in, params=self._params(offset_to_ground))
+                tpos, tquat, cols, offs, chunk, burn_in, params=self._params(offset_to_ground))
         else:
             items = make_items(offs, chunk=chunk, burn_in=burn_in)
-            out, iters, _ = self._engine.ik_solve(tpos, tquat, self._columns(list(body_names)), items, params=self._params(offset_to_ground))
+            out, iters, _ = self._engine.ik_solve(tpos, tquat, cols, items, params=self._params(offset_to_ground))
         if is_np:
             out = out.cpu().numpy()
             iters = iters.cpu().numpy() if iters is not None else None
