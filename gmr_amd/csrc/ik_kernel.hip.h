@@ -833,38 +833,38 @@ __device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool 
     }
     // ---- elimination of local pivot k in every group; the limb pivots first, then (after the cross-group sum) the core ----
     double myinvd = 1.0;
-    // pivot k of every group at once: d_k and b_k come from the pivot lane, column k (= row k by symmetry) entry by entry from
-    // the lanes below it, all by row_newbcast -- no LDS, no barrier
-    auto step = [&](auto K) {
+    // Pivot k of every group at once: d_k and b_k come from the pivot lane, column k (= row k by symmetry) entry by entry from
+    // the lanes below it, all by row_newbcast -- no LDS, no barrier.  The steps nest: step k runs with the rows a >= k enabled
+    // and narrows EXEC to a > k for its updates and for everything after it, so a step costs one compare instead of two
+    // masked regions; rows above the pivot simply stay switched off until the back-substitution.  `myinvd` is overwritten by
+    // every step a row still takes part in, the last of which is its own.
+    auto elim = [&](auto &&self, auto K) -> void {
       constexpr int k = K;
-      const double invd = fast_rcp(group_bcast<k>(R[k]));
+      if constexpr (k >= 6 && k <= 10) {
+        if (k == launder_uniform(nl)) {  // first core pivot: every copy of the core block / rhs <- sum over the four groups.  Only core rows
+#pragma unroll                           // (a >= nl) are enabled here, in every group alike; limb columns are already zero in them
+          for (int b = 6; b < 16; b++) R[b] = group_sum4(R[b]);
+          bb = group_sum4(bb);
+        }
+      }
+      const double ck = R[k];  // this row's entry in the pivot column
+      const double invd = fast_rcp(group_bcast<k>(ck));
       const double bk = group_bcast<k>(bb);
-      const int ak = launder(a);  // compare here, per step: 32 lane masks hoisted out of the loop would cost 64 SGPRs
-      if (ak == k) { myinvd = invd; R[k] = 0.0; }
-      if (ak > k) {  // rows below the pivot (their lanes are exactly the sources of the broadcasts inside)
-        const double u = R[k] * invd;
-        static_for<k + 1, 16>([&](auto J) {
-          constexpr int jj = J;
-          R[jj] -= u * group_bcast<jj>(R[k]);
-        });
-        bb -= u * bk;
-        R[k] = 0.0;  // dead from here; zero so that the back-substitution needs no triangle mask
+      myinvd = invd;
+      const double u = ck * invd;
+      R[k] = 0.0;  // dead from here (also the pivot's own diagonal): the back-substitution needs no triangle mask
+      if constexpr (k < 15) {
+        if (launder(a) > k) {  // rows below the pivot (their lanes are exactly the sources of the broadcasts inside)
+          static_for<k + 1, 16>([&](auto J) {
+            constexpr int jj = J;
+            R[jj] -= u * group_bcast<jj>(ck);
+          });
+          bb -= u * bk;
+          self(self, std::integral_constant<int, k + 1>{});
+        }
       }
     };
-    static_for<0, 6>([&](auto K) { step(K); });  // nl >= 6 (the core has at most 10 dofs)
-    static_for<6, 10>([&](auto K) { if (K < launder_uniform(nl)) step(K); });  // wave-uniform scalar branch
-    // every copy of the core block / rhs <- sum over the four groups
-#pragma unroll
-    for (int b = 6; b < 16; b++) {  // columns 6 .. nl-1 are limb columns: already zero in the core rows, summing them is harmless
-      const double t = group_sum4(R[b]);
-      R[b] = core_row ? t : R[b];
-    }
-    {
-      const double t = group_sum4(bb);
-      bb = core_row ? t : bb;
-    }
-    static_for<6, 10>([&](auto K) { if (K >= launder_uniform(nl)) step(K); });
-    static_for<10, 16>([&](auto K) { step(K); });
+    elim(elim, std::integral_constant<int, 0>{});
     // ---- back-substitution, k = 15 .. 0: x_k = (y_k - sum_{b>k} R_k[b] x_b) / d_k ----
     static_for_down<0, 16>([&](auto K) {  // R[k] is 0 on and left of the diagonal (cleared by the elimination)
       constexpr int k = K;
