@@ -804,7 +804,6 @@ __device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool 
     else if (lo > 0.0) { x = lo; status = 1; }
     else if (hi < 0.0) { x = hi; status = 2; }
   }
-  const double gtol = 1e-10 * (1.0 + wave_max(owner ? fabs(ci) : 0.0));
   constexpr int kMaxIt = 6 * 64 + 16;
   int it = 0;
   for (; it < kMaxIt; ++it) {
@@ -908,6 +907,7 @@ __device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool 
     const double g = ci + hx;
     const double viol = (owner && status != 0) ? (status == 1 ? -g : g) : -INFINITY;
     const double worst = wave_max(viol);
+    const double gtol = 1e-10 * (1.0 + wave_max(owner ? fabs(ci) : 0.0));  // only solves with a working set get here (~4 %)
     if (!(worst > gtol)) { ++it; break; }
     const u64 whr = __ballot(viol == worst);
     if (lane == (int)__builtin_ctzll(whr)) status = 0;
