@@ -808,18 +808,19 @@ __device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool 
   int it = 0;
   for (; it < kMaxIt; ++it) {
     lane = launder(lane);
-    // effective status / value of every structured row (copies follow their owner, padding is pinned at 0)
-    const int st_src = __shfl(status, a);      // group 0's lane with my local index
-    const double x_src = __shfl(x, a);
-    const int st = pad ? 3 : (shadow ? st_src : status);
-    const double xe = pad ? 0.0 : (shadow ? x_src : x);
-    const bool fixed_me = st != 0;
-    const u64 fixed = __ballot(fixed_me && !pad);
     double R[16];
 #pragma unroll
     for (int b = 0; b < 16; b++) R[b] = Hs[b * 64 + lane];
     double bb = (owner ? -ci : 0.0);
-    if (fixed) {  // wave-uniform: rows/columns of the working set become the identity, their values move to the rhs
+    if (__ballot(owner && status != 0)) {  // wave-uniform, ~4 % of the solves: a working set exists
+      // effective status / value of every structured row (copies follow their owner, padding is pinned at 0); rows / columns
+      // of the working set become the identity, their values move to the rhs
+      const int st_src = __shfl(status, a);      // group 0's lane with my local index
+      const double x_src = __shfl(x, a);
+      const int st = pad ? 3 : (shadow ? st_src : status);
+      const double xe = pad ? 0.0 : (shadow ? x_src : x);
+      const bool fixed_me = st != 0;
+      const u64 fixed = __ballot(fixed_me && !pad);
       const unsigned fg = (unsigned)(fixed >> gb) & 0xffffu;  // my group's fixed columns
       static_for<0, 16>([&](auto B) {
         constexpr int b = B;
