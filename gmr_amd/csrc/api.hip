@@ -407,7 +407,7 @@ int build_device_model(gmr_model *m) {
   // ---- LDS layout of the IK kernel (doubles).  Lifetimes inside one solve:
   //   poses (FK .. screws) | Bt (task blocks .. composites) | Bc (composites .. F)   -> Bc overwrites the dead poses
   //   S, F (screws / F .. H assembly)                                                 -> the factorisation's broadcast rows Lb overwrite S
-  //   H (H assembly .. QP) overwrites [Bt | poses/Bc];  V (structured QP only): c in / dq out, per dof
+  //   H (H assembly .. QP) overwrites [Bt | poses/Bc]
   const int ntmax = std::max(h.ntask[0], h.ntask[1]), ncmax = std::max(ncomp[0], ncomp[1]);
   const bool sq = sq_ok && !m->force_generic;
   gmr::LdsLayout &L = m->lay;  // (named L here; the composite plan below needs the byte offsets)
@@ -419,7 +419,6 @@ int build_device_model(gmr_model *m) {
   L.q = o; o += even(nq);
   L.tp = o; o += even(3 * ns);
   L.tq = o; o += 4 * ns;
-  L.V = o; o += sq ? even(n_act) : 0;
   L.bodyc = GMR_IK_STAGE_TREE ? o : -1; o += GMR_IK_STAGE_TREE ? even(gmr::kBodyC * nb) : 0;
   L.S = o; L.Lb = o; o += std::max(6 * nvp, sq ? 128 : 2 * (nvp + 2));
   L.F = o; o += 6 * nvp;

@@ -116,7 +116,7 @@ struct DevModel {
 struct LdsLayout {
   // offsets in doubles.  zero: block of zeros; hplan / cplan: the staged H-pair and composite plans; Lb (generic QP broadcast
   // rows) aliases S; Bc aliases the poses; H aliases [B | poses / Bc] (all dead during the QP)
-  int zero, hplan, cplan, q, tp, tq, S, F, Lb, V, bodyc, xpos, xquat, B, Bc, H, total_doubles;
+  int zero, hplan, cplan, q, tp, tq, S, F, Lb, bodyc, xpos, xquat, B, Bc, H, total_doubles;
 };
 
 struct IkLaunch {
@@ -990,6 +990,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
   const int sq_g = SQ ? (int)m.sq_gdof[lane] : -1;
   const bool sq_own = SQ ? m.sq_owner[lane] != 0 : false, sq_pad = sq_g < 0;
   const int sq_mydiag = SQ && real_row ? m.sq_diag[lane] : 0;
+  const int sq_owner_lane = SQ && real_row ? m.sq_lane_of_dof[lane] : 0;  // the QP lane that owns this lane's dof
   // joint range and qpos address of the dof this lane owns in the structured QP layout, kept in registers: the limits are
   // rebuilt every solve and must not wait for L2.  Unlimited dofs get an infinite range.
   int sq_qadr = 0;
@@ -998,7 +999,6 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
     sq_qadr = m.aqadr[sq_g];
     if (m.alimited[sq_g]) { sq_rlo = m.arange[2 * sq_g]; sq_rhi = m.arange[2 * sq_g + 1]; }
   }
-  double *V = lds + lay.V;
   int sq_status = 0;
   for (int i = lane; i < nq; i += 64) q[i] = w.init_row >= 0 ? L.qinit[(size_t)w.init_row * nq + i] : m.qpos0[i];
   int status = real_row ? 0 : 3;
@@ -1128,26 +1128,28 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         // ---- screws S_i (world frame, about the origin) ----
         double Si[6] = {0, 0, 0, 0, 0, 0};
         GMR_DUP(4) if (real_row) {
-          if (a_kind < 3) {
-            Si[a_kind] = 1.0;  // root translation: world aligned
+          // every dof as an axis in its body's frame: the hinge axis, or e_k for the six root dofs (translations are world
+          // aligned and carry no moment) -- one code path, selects only at the two ends
+          const double qb[4] = {xquat[4 * a_body], xquat[4 * a_body + 1], xquat[4 * a_body + 2], xquat[4 * a_body + 3]};
+          const double xb[3] = {xpos[3 * a_body], xpos[3 * a_body + 1], xpos[3 * a_body + 2]};
+          double a_axis[3];
+          if constexpr (GMR_IK_STAGE_TREE != 0) {  // the staged joint tree carries the axis: no L2 read inside the solve
+            const double *bc = bodyc + kBodyC * a_body + 7;
+            a_axis[0] = bc[0]; a_axis[1] = bc[1]; a_axis[2] = bc[2];
           } else {
-            const double qb[4] = {xquat[4 * a_body], xquat[4 * a_body + 1], xquat[4 * a_body + 2], xquat[4 * a_body + 3]};
-            const double xb[3] = {xpos[3 * a_body], xpos[3 * a_body + 1], xpos[3 * a_body + 2]};
             const int ab = launder(a_body);
-            double a_axis[3];
-            if constexpr (GMR_IK_STAGE_TREE != 0) {  // the staged joint tree carries the axis: no L2 read inside the solve
-              const double *bc = bodyc + kBodyC * a_body + 7;
-              a_axis[0] = bc[0]; a_axis[1] = bc[1]; a_axis[2] = bc[2];
-            } else {
-              a_axis[0] = m.axis[3 * ab]; a_axis[1] = m.axis[3 * ab + 1]; a_axis[2] = m.axis[3 * ab + 2];
-            }
-            double R[9], ax[3], mo[3];
-            q2mat(qb, R);
-            if (a_kind < 6) { ax[0] = R[a_kind - 3]; ax[1] = R[a_kind]; ax[2] = R[a_kind + 3]; }  // root-body-frame axes
-            else mv(R, a_axis, ax);
-            cross(xb, ax, mo);
-            Si[0] = mo[0]; Si[1] = mo[1]; Si[2] = mo[2]; Si[3] = ax[0]; Si[4] = ax[1]; Si[5] = ax[2];
+            a_axis[0] = m.axis[3 * ab]; a_axis[1] = m.axis[3 * ab + 1]; a_axis[2] = m.axis[3 * ab + 2];
           }
+          const bool is_root = a_kind < 6, is_trans = a_kind < 3;
+          const int kk = is_trans ? a_kind : a_kind - 3;
+#pragma unroll
+          for (int i = 0; i < 3; i++) a_axis[i] = is_root ? (kk == i ? 1.0 : 0.0) : a_axis[i];
+          double R[9], ax[3], mo[3];
+          q2mat(qb, R);
+          mv(R, a_axis, ax);
+          cross(xb, ax, mo);
+#pragma unroll
+          for (int i = 0; i < 3; i++) { Si[i] = is_trans ? a_axis[i] : mo[i]; Si[3 + i] = is_trans ? 0.0 : ax[i]; }
 #pragma unroll
           for (int k = 0; k < 6; k++) S[6 * lane + k] = Si[k];
         }
@@ -1223,13 +1225,14 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
           if (real_row) {
             const double *Fi = F + 6 * lane;
             Hm[sq_mydiag] = Si[0] * Fi[0] + Si[1] * Fi[1] + Si[2] * Fi[2] + Si[3] * Fi[3] + Si[4] * Fi[4] + Si[5] * Fi[5] + diag;
-            V[lane] = ci;
           }
           if (sq_pad) Hm[(lane & 15) * 64 + lane] = 1.0;
           __syncthreads();
           GMR_STAMP(7);
-          const int gi = launder(sq_own ? sq_g : 0);
-          const double s_ci = sq_own ? V[gi] : 0.0;
+          // c from the dof-indexed lane to the lane that owns the dof in the QP layout (and dq back below): a lane permute,
+          // no LDS memory and no barrier
+          const double c_in = __shfl(ci, sq_own ? sq_g : 0);
+          const double s_ci = sq_own ? c_in : 0.0;
           // mink ConfigurationLimit, evaluated by the lane that owns the dof in the QP layout: -gain (q - lower) <= dq <= gain (upper - q)
           const double qv = q[sq_qadr];
           const double s_lo = fmax(-prm.limit_gain * (qv - sq_rlo), -1e30), s_hi = fmin(prm.limit_gain * (sq_rhi - qv), 1e30);
@@ -1238,10 +1241,8 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
           if (GMR_DUP_PHASE == 8) { int st2 = sq_status; double x2; (void)box_qp_struct(lane, m.sq_nlimb, sq_own, sq_pad, Hm, s_ci, s_lo, s_hi, st2, x2); asm volatile("" :: "v"(x2)); }
 #endif
           qit = box_qp_struct(lane, m.sq_nlimb, sq_own, sq_pad, Hm, s_ci, s_lo, s_hi, sq_status, xs);
-          __syncthreads();
-          if (sq_own) V[sq_g] = xs;  // c is dead: the same array carries dq back to the dof-indexed lanes
-          __syncthreads();
-          dq = real_row ? V[lane] : 0.0;
+          const double x_back = __shfl(xs, sq_owner_lane);
+          dq = real_row ? x_back : 0.0;
         } else {
 #pragma unroll
           for (int i = 0; i < (NVP * NVP + 63) / 64; i++)
