@@ -7,7 +7,7 @@
 // concurrently, one per wavefront; nothing is exchanged between them.
 //
 // Lane roles change per phase (all state that crosses phases lives in LDS):
-//   FK            lane = body        pointer jumping up the joint tree: ceil(log2(depth+1)) LDS round trips
+//   FK            lane = body        pointer jumping up the joint tree: ceil(log2(depth+1)) rounds of lane permutes
 //   residual      lane = task        SE3 log of T_body^-1 T_target, |e| by a DPP wave reduction
 //   task blocks   lane = task        6x6 "task inertia" B_t = A_t' W^2 A_t and g_t = A_t' W^2 e_t
 //   composites    lane = (half,elt)  B^c = sum of B_t below a joint (composite-rigid-body style), two composites per pass
@@ -301,8 +301,9 @@ __device__ __forceinline__ void cross(const double a[3], const double b[3], doub
 // xpos_j = xpos_p + R(xquat_p) pos_j ;  xquat_j = xquat_p (x) quat_j (x) [cos t/2, sin t/2 axis_j]
 // evaluated by pointer jumping instead of walking the tree level by level: every lane holds its body's pose
 // relative to an ancestor and, each round, composes it with that ancestor's own relative pose (which doubles
-// the distance folded), so a chain of depth d needs ceil(log2 d) LDS round trips instead of d.  The ancestor
-// of each round is static per body (m.fkanc, one byte per round, 0xff = already in the world frame).
+// the distance folded), so a chain of depth d needs ceil(log2 d) rounds instead of d.  The ancestor of each
+// round is static per body (m.fkanc, one byte per round, 0xff = already in the world frame); its pose is
+// fetched from its lane's registers by ds_bpermute.
 // The joint tree (per-body pos / quat / axis / joint type / ancestor plan) is staged in LDS once per wavefront.
 __device__ __forceinline__ void qrot(const double q[4], const double v[3], double o[3]) {  // R(q) v, q unit
   const double tx = 2.0 * (q[2] * v[2] - q[3] * v[1]), ty = 2.0 * (q[3] * v[0] - q[1] * v[2]), tz = 2.0 * (q[1] * v[1] - q[2] * v[0]);
@@ -360,18 +361,15 @@ __device__ __forceinline__ void fk_phase(const DevModel &m, const double *bodyc,
     const double jq[4] = {c, s * ax[0], s * ax[1], s * ax[2]};
     qmul(bq, jq, ql);
   }
-  if (has) {
-    xpos[3 * lane] = pos[0]; xpos[3 * lane + 1] = pos[1]; xpos[3 * lane + 2] = pos[2];
-    xquat[4 * lane] = ql[0]; xquat[4 * lane + 1] = ql[1]; xquat[4 * lane + 2] = ql[2]; xquat[4 * lane + 3] = ql[3];
-  }
-  __syncthreads();
+  // lane = body, so "my ancestor's pose" is another lane's registers: fetched through the LDS crossbar (ds_bpermute, no LDS
+  // memory, no bank conflicts, no write-then-read round trip per round); only the final poses are stored
   const int nr = nrounds;
   for (int r = 0; r < nr; ++r) {
     const int a = (int)((ancs >> (8 * r)) & 0xff);
     const bool act = a != 0xff;
     const int aa = act ? a : 0;
-    const double qa[4] = {xquat[4 * aa], xquat[4 * aa + 1], xquat[4 * aa + 2], xquat[4 * aa + 3]};
-    const double pa[3] = {xpos[3 * aa], xpos[3 * aa + 1], xpos[3 * aa + 2]};
+    const double qa[4] = {__shfl(ql[0], aa), __shfl(ql[1], aa), __shfl(ql[2], aa), __shfl(ql[3], aa)};
+    const double pa[3] = {__shfl(pos[0], aa), __shfl(pos[1], aa), __shfl(pos[2], aa)};
     if (act) {
       double t[3], qo[4];
       qrot(qa, pos, t);
@@ -379,11 +377,13 @@ __device__ __forceinline__ void fk_phase(const DevModel &m, const double *bodyc,
       pos[0] = pa[0] + t[0]; pos[1] = pa[1] + t[1]; pos[2] = pa[2] + t[2];
       ql[0] = qo[0]; ql[1] = qo[1]; ql[2] = qo[2]; ql[3] = qo[3];
       if (r == nr - 1 || ((ancs >> (8 * (r + 1))) & 0xff) == 0xff) qrenorm(ql);  // reached the world frame
-      xpos[3 * lane] = pos[0]; xpos[3 * lane + 1] = pos[1]; xpos[3 * lane + 2] = pos[2];
-      xquat[4 * lane] = ql[0]; xquat[4 * lane + 1] = ql[1]; xquat[4 * lane + 2] = ql[2]; xquat[4 * lane + 3] = ql[3];
     }
-    __syncthreads();
   }
+  if (has) {
+    xpos[3 * lane] = pos[0]; xpos[3 * lane + 1] = pos[1]; xpos[3 * lane + 2] = pos[2];
+    xquat[4 * lane] = ql[0]; xquat[4 * lane + 1] = ql[1]; xquat[4 * lane + 2] = ql[2]; xquat[4 * lane + 3] = ql[3];
+  }
+  __syncthreads();
 }
 
 // ------------------------------------------------------------------ residual, lane = task
