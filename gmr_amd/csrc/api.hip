@@ -413,7 +413,7 @@ int build_device_model(gmr_model *m) {
   gmr::LdsLayout &L = m->lay;  // (named L here; the composite plan below needs the byte offsets)
   auto even = [](int x) { return (x + 1) & ~1; };
   int o = 0;
-  L.zero = o; o += gmr::kBT + 1;  // a block of zeros: the absent sources of the composite plan (never aliased)
+  L.zero = o; o += gmr::kBT;  // a block of zeros: the absent sources of the composite plan (never aliased)
   const int npairp_host = ((int)hpair.size() + 63) / 64 * 64;
   L.hplan = o; o += npairp_host;  // H pair plan, 8 bytes per entry (staged once per wavefront)
   L.q = o; o += even(nq);
@@ -426,14 +426,14 @@ int build_device_model(gmr_model *m) {
   const int bt = even(gmr::kBT * ntmax), px = std::max(even(7 * nb), even(gmr::kBT * ncmax));
   L.xpos = o + bt; L.xquat = L.xpos + even(3 * nb); L.Bc = o + bt;
   o += std::max(bt + px, (sq ? 1024 : nvp * nvp) + 2);  // + a dummy slot for the unused lanes of the pair rounds
-  L.cplan = o;  // composite plan, 16 bytes per (table, pass, half-wave); sized once the passes are scheduled (below)
+  L.cplan = o;  // composite plan, 16 bytes per (table, pass, quarter-wave); sized once the passes are scheduled (below)
   L.total_doubles = o;
   m->lds_bytes = o * (int)sizeof(double);
   m->nvp = nvp;
   m->n_act = n_act;
-  // ---- composite plan: passes of <= 2 entries, an entry = one composite summed from <= 4 blocks, children before parents ----
+  // ---- composite plan: passes of <= 4 entries, an entry = one composite summed from <= 4 blocks, children before parents ----
   if (m->lds_bytes > 65535) { set_err(m, "model needs %d bytes of LDS per wavefront (plan offsets are 16 bit)", m->lds_bytes); return GMR_EUNSUPPORTED; }
-  std::vector<uint32_t> comp_plan((size_t)2 * gmr::kMaxCompPass * 2 * 4, 0u);
+  std::vector<uint32_t> comp_plan((size_t)2 * gmr::kMaxCompPass * 4 * 4, 0u);
   int ncpass[2] = {0, 0};
   for (int k = 0; k < 2; ++k) {
     struct Entry { int dst; std::vector<int> src; std::vector<int> deps; int done_pass = -1; int height = 0; };
@@ -471,11 +471,11 @@ int build_device_model(gmr_model *m) {
     auto block_off = [&](int id) { return id >= 64 ? coff + gmr::kBT * 8 * (id - 64) : boff + gmr::kBT * 8 * id; };
     while (done < ne) {
       if (pass >= gmr::kMaxCompPass) { set_err(m, "composite plan of table %d needs more than %d passes", k + 1, gmr::kMaxCompPass); return GMR_EUNSUPPORTED; }
-      int pick[2] = {-1, -1};
-      for (int slot = 0; slot < 2; ++slot) {
+      int pick[4] = {-1, -1, -1, -1};
+      for (int slot = 0; slot < 4; ++slot) {
         int best = -1;
         for (int i = 0; i < ne; ++i) {
-          if (ent[i].done_pass >= 0 || i == pick[0]) continue;
+          if (ent[i].done_pass >= 0 || i == pick[0] || i == pick[1] || i == pick[2]) continue;
           bool ready = true;
           for (int d : ent[i].deps) ready = ready && ent[d].done_pass >= 0 && ent[d].done_pass < pass;
           if (ready && (best < 0 || ent[i].height > ent[best].height)) best = i;
@@ -483,9 +483,9 @@ int build_device_model(gmr_model *m) {
         pick[slot] = best;
       }
       if (pick[0] < 0) { set_err(m, "internal: composite plan stalled"); return GMR_EINVAL; }
-      for (int half = 0; half < 2; ++half) {
-        uint32_t *row = comp_plan.data() + ((size_t)(k * gmr::kMaxCompPass + pass) * 2 + half) * 4;
-        const int ei = pick[half];
+      for (int quarter = 0; quarter < 4; ++quarter) {
+        uint32_t *row = comp_plan.data() + ((size_t)(k * gmr::kMaxCompPass + pass) * 4 + quarter) * 4;
+        const int ei = pick[quarter];
         uint32_t so[4] = {(uint32_t)zoff, (uint32_t)zoff, (uint32_t)zoff, (uint32_t)zoff}, dst = (uint32_t)scratch;
         if (ei >= 0) {
           for (size_t j = 0; j < ent[ei].src.size(); ++j) so[j] = (uint32_t)block_off(ent[ei].src[j]);
@@ -493,13 +493,13 @@ int build_device_model(gmr_model *m) {
         }
         row[0] = so[0] | (so[1] << 16); row[1] = so[2] | (so[3] << 16); row[2] = dst; row[3] = 0;
       }
-      for (int slot = 0; slot < 2; ++slot)
+      for (int slot = 0; slot < 4; ++slot)
         if (pick[slot] >= 0) { ent[pick[slot]].done_pass = pass; ++done; }
       ++pass;
     }
     ncpass[k] = pass;
   }
-  m->lay.total_doubles += 4 * (ncpass[0] + ncpass[1]);
+  m->lay.total_doubles += 8 * (ncpass[0] + ncpass[1]);
   m->lds_bytes = m->lay.total_doubles * (int)sizeof(double);
   if (m->lds_bytes > 65535) { set_err(m, "model needs %d bytes of LDS per wavefront (plan offsets are 16 bit)", m->lds_bytes); return GMR_EUNSUPPORTED; }
   // ---- H assembly plan: per pair the LDS byte offsets of S_j, F_i and of the two entries of H it fills ----

@@ -70,7 +70,7 @@ typedef unsigned long long u64;
 #define GMR_IK_WAVES_PER_SIMD 2
 #endif
 
-constexpr int kBT = 27;  // doubles per task block: LL(6) LA(9) AA(6) g(6), stored "by column": element 3k + s with s = 0..2 and
+constexpr int kBT = 28;  // doubles per task block: LL(6) LA(9) AA(6) g(6) + 1 pad (never read), stored "by column": element 3k + s, s = 0..2,
 // k: 0 LL(s,s)  1 LL(s,s+1)  2..4 LA(s,s), LA(s,s+1), LA(s,s+2)  5 AA(s,s)  6 AA(s,s+1)  7 gl_s  8 ga_s   (indices mod 3)
 // -- the order in which three lanes per task (one per column s) produce it in task_block_quad
 __host__ __device__ constexpr int bt_ll(int i, int j) { return i == j ? i : ((j - i + 3) % 3 == 1 ? 3 + i : 3 + j); }
@@ -108,9 +108,9 @@ struct DevModel {
   // H assembly plan, one entry per structurally non-zero off-diagonal pair (dof j strictly above dof i), padded to a multiple
   // of 64 with entries that land in the dummy slots: LDS byte offsets {S_j | F_i << 16, H[i][j] | H[j][i] << 16}
   uint2 hplan[kMaxPairsPadded];
-  // composite plan per table, pass and half-wave: LDS byte offsets of four source blocks and the destination block
-  // {s0|s1<<16, s2|s3<<16, dst, -}; absent sources point at the zero block, an idle half at a scratch block
-  uint4 comp_plan[2 * kMaxCompPass * 2];
+  // composite plan per table, pass and quarter-wave: LDS byte offsets of four source blocks and the destination block
+  // {s0|s1<<16, s2|s3<<16, dst, -}; absent sources point at the zero block, an idle quarter at a scratch block
+  uint4 comp_plan[2 * kMaxCompPass * 4];
 };
 
 struct LdsLayout {
@@ -962,14 +962,14 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
   if constexpr (GMR_IK_STAGE_TREE != 0) stage_tree(m, lane, bodyc);
   // Once per wavefront: the zero block (absent sources of the composite plan) and the two phase plans, from the L2-resident
   // model into LDS, where a plan entry costs one short-latency read per pass instead of an L2 round trip.
-  if (lane < kBT + 1) lds[lay.zero + lane] = 0.0;
+  if (lane < kBT) lds[lay.zero + lane] = 0.0;
   {
     uint2 *hp = reinterpret_cast<uint2 *>(lds + lay.hplan);
     for (int i = lane; i < m.npairp; i += 64) hp[i] = m.hplan[i];
     uint4 *cp = reinterpret_cast<uint4 *>(lds + lay.cplan);
-    const int n0 = 2 * m.ncpass[0], n1 = 2 * m.ncpass[1];
-    if (lane < n0) cp[lane] = m.comp_plan[lane];
-    if (lane < n1) cp[n0 + lane] = m.comp_plan[2 * kMaxCompPass + lane];
+    const int n0 = 4 * m.ncpass[0], n1 = 4 * m.ncpass[1];
+    for (int i = lane; i < n0; i += 64) cp[i] = m.comp_plan[i];
+    for (int i = lane; i < n1; i += 64) cp[n0 + i] = m.comp_plan[4 * kMaxCompPass + i];
   }
   const gmr_work_item w = L.items[blockIdx.x];
   const gmr_ik_params prm = L.prm;
@@ -1156,22 +1156,26 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         __syncthreads();
         GMR_STAMP(4);
         // ---- composites: Bc[c] = sum of task blocks below the joint ----
-        GMR_DUP(5) {  // Composites are built children-first by a host-made plan: each pass, lanes 0..26 and 32..58 each sum up to four
-                      // blocks (task blocks or finished composites) into one composite, element per lane.  A lane's plan entry is
-                      // four source byte offsets (absent ones point at a zero) and a destination; no masks, no selects.  Same
-                      // wave, so LDS program order makes a pass see the previous one's writes without a barrier.
+        GMR_DUP(5) {  // Composites are built children-first by a host-made plan: each pass, every quarter of the wave (16 lanes, 14 used,
+                      // two block elements per lane) sums up to four blocks (task blocks or finished composites) into one
+                      // composite.  A quarter's plan entry is four source block offsets (absent ones point at the zero block) and a
+                      // destination; no masks, no selects.  Same wave, so LDS program order makes a pass see the previous one's
+                      // writes without a barrier.
           const int np = m.ncpass[tab];
-          if ((lane & 31) < kBT) {  // element of the block; lanes 27..31 of each half idle
+          if ((lane & 15) < kBT / 2) {
             char *lb = reinterpret_cast<char *>(lds);
-            const unsigned el8 = 8u * (lane & 31);
-            const uint4 *plan = reinterpret_cast<const uint4 *>(lds + lay.cplan) + (tab ? 2 * m.ncpass[0] : 0) + (lane >> 5);
+            const unsigned el16 = 16u * (lane & 15);
+            const uint4 *plan = reinterpret_cast<const uint4 *>(lds + lay.cplan) + (tab ? 4 * m.ncpass[0] : 0) + (lane >> 4);
             uint4 nxt = plan[0];
             for (int p = 0; p < np; ++p) {
               const uint4 cur = nxt;
-              if (p + 1 < np) nxt = plan[2 * (p + 1)];
-              const double v0 = *reinterpret_cast<const double *>(lb + ((cur.x & 0xffffu) + el8)), v1 = *reinterpret_cast<const double *>(lb + ((cur.x >> 16) + el8));
-              const double v2 = *reinterpret_cast<const double *>(lb + ((cur.y & 0xffffu) + el8)), v3 = *reinterpret_cast<const double *>(lb + ((cur.y >> 16) + el8));
-              *reinterpret_cast<double *>(lb + (cur.z + el8)) = (v0 + v1) + (v2 + v3);
+              if (p + 1 < np) nxt = plan[4 * (p + 1)];
+              const double2 v0 = *reinterpret_cast<const double2 *>(lb + ((cur.x & 0xffffu) + el16)), v1 = *reinterpret_cast<const double2 *>(lb + ((cur.x >> 16) + el16));
+              const double2 v2 = *reinterpret_cast<const double2 *>(lb + ((cur.y & 0xffffu) + el16)), v3 = *reinterpret_cast<const double2 *>(lb + ((cur.y >> 16) + el16));
+              double2 sum;
+              sum.x = (v0.x + v1.x) + (v2.x + v3.x);
+              sum.y = (v0.y + v1.y) + (v2.y + v3.y);
+              *reinterpret_cast<double2 *>(lb + (cur.z + el16)) = sum;
             }
           }
         }
