@@ -100,7 +100,12 @@ def main():
                     "form profiled under rocprofv3 so the kernel's average duration is that of the timed launch")
     args = ap.parse_args()
 
-    rank, world, local = gdist.init_from_env()
+    # Rehearsal of the N > 1 path on a single-GPU box: GMR_BENCH_BACKEND=gloo GMR_BENCH_SHARE_GPU=1 runs every rank on cuda:0
+    # with CPU collectives (everything but RCCL itself); the real run uses the defaults (nccl = RCCL, one GPU per rank).
+    rank, world, local = gdist.init_from_env(os.environ.get("GMR_BENCH_BACKEND") or None)
+    if os.environ.get("GMR_BENCH_SHARE_GPU") == "1":
+        local = 0
+    on_rccl = world > 1 and torch.distributed.get_backend() == "nccl"
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
@@ -133,7 +138,10 @@ def main():
 
     def barrier():
         if world > 1:
-            torch.distributed.barrier(device_ids=[local])  # RCCL: the barrier runs on this rank's own GPU
+            if on_rccl:
+                torch.distributed.barrier(device_ids=[local])  # RCCL: the barrier runs on this rank's own GPU
+            else:
+                torch.distributed.barrier()
 
     for _ in range(args.warmup):
         step()
@@ -150,7 +158,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if on_rccl else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))

@@ -491,3 +491,21 @@ def test_error1_equals_error2_for_same_map_tables():
     for f in range(5):
         g.retarget(_frames(pos, quat, names, f))
         assert g.error1() == g.error2() and g.error1() > 0
+
+
+def test_bench_two_rank_path_rehearsal():
+    """bench.py's N > 1 path (rank discovery, model broadcast, barrier + max-over-ranks timing, rank-0 JSON) with two ranks
+    sharing this box's one GPU and gloo collectives -- everything the 8-GPU run does except RCCL itself."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GMR_BENCH_BACKEND="gloo", GMR_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--clips", "64", "--frames", "60"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["frames_per_step"] == 2 * 64 * 60
+    assert d["value"] > 0 and abs(d["value"] - d["config"]["frames_per_step"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
