@@ -33,6 +33,9 @@ struct gmr_model {
   size_t dev_bytes = 0;
   gmr::DevModel dm{};                      // host copy of the device model (scalars are read back by the host API)
   const gmr::DevModel *dm_dev = nullptr;  // the struct in device memory: the one model argument of the IK kernels
+  const gmr::DevModel *dm_eval_dev = nullptr;  // the same with the full body tree (gmr_evaluate)
+  gmr::LdsLayout lay_eval{};
+  int lds_bytes_eval = 0;
   gmr::FkTree fk{};
   gmr::LdsLayout lay{};
   int nvp = 0, n_act = 0, lds_bytes = 0, fk_lds_bytes = 0, fk_lds_bytes_min = 0;  // _min: the min-height mode has no output stage
@@ -187,6 +190,20 @@ int build_device_model(gmr_model *m) {
     while (b > a) b = parent[b];
     return b == a;
   };
+  // ---- bodies the IK needs: the task bodies and their ancestors.  Everything else (the 14 finger links of
+  //      unitree_g1_with_hands, head / hand cosmetics) never enters a residual or a screw, so the IK kernel works on this
+  //      pruned tree (fewer lanes, less LDS per wavefront); gmr_evaluate keeps the full tree for configuration.data.xpos. ----
+  std::vector<int> keep, bmap(nb, -1);
+  {
+    std::vector<char> needed(nb, 0);
+    needed[0] = 1;
+    for (int k = 0; k < 2; ++k)
+      for (int t = 0; t < h.ntask[k]; ++t)
+        for (int b = tbody[k * GMR_MAX_TASKS + t]; b >= 0 && !needed[b]; b = parent[b]) needed[b] = 1;
+    for (int b = 0; b < nb; ++b)
+      if (needed[b]) { bmap[b] = (int)keep.size(); keep.push_back(b); }
+  }
+  const int nb_ik = (int)keep.size();
   // ---- active dofs: root 6 + hinges with at least one task (either table) at or below them ----
   std::vector<int> abody, akind, aqadr, alim;
   std::vector<double> arange;
@@ -255,24 +272,35 @@ int build_device_model(gmr_model *m) {
       p -= w;
     }
   }
-  // ---- FK pointer-jumping plan: ancestor folded in each round, one byte per round ----
-  int fkrounds = 0;
-  while ((1 << fkrounds) <= maxdepth) ++fkrounds;
-  if (fkrounds > 8) { set_err(m, "tree too deep"); return GMR_EUNSUPPORTED; }
-  std::vector<u64> fkanc(nb, ~0ull);
-  {
-    std::vector<int> anc(parent, parent + nb);
-    for (int r = 0; r < fkrounds; ++r) {
-      std::vector<int> nxt(nb, -1);
-      for (int b = 0; b < nb; ++b) {
-        const u64 byte = anc[b] < 0 ? 0xffull : (u64)anc[b];
-        fkanc[b] = (fkanc[b] & ~(0xffull << (8 * r))) | (byte << (8 * r));
-        nxt[b] = anc[b] < 0 ? -1 : anc[anc[b]];
+  // ---- FK pointer-jumping plan: ancestor folded in each round, one byte per round (for the pruned IK tree and the full tree) ----
+  auto fk_plan = [&](const std::vector<int> &par, std::vector<u64> &plan, int &rounds) -> bool {
+    const int n = (int)par.size();
+    int maxd = 0;
+    std::vector<int> dep(n, 0);
+    for (int b2 = 1; b2 < n; ++b2) { dep[b2] = dep[par[b2]] + 1; maxd = std::max(maxd, dep[b2]); }
+    rounds = 0;
+    while ((1 << rounds) <= maxd) ++rounds;
+    if (rounds > 8) return false;
+    plan.assign(n, ~0ull);
+    std::vector<int> anc(par);
+    for (int r = 0; r < rounds; ++r) {
+      std::vector<int> nxt(n, -1);
+      for (int b2 = 0; b2 < n; ++b2) {
+        const u64 byte = anc[b2] < 0 ? 0xffull : (u64)anc[b2];
+        plan[b2] = (plan[b2] & ~(0xffull << (8 * r))) | (byte << (8 * r));
+        nxt[b2] = anc[b2] < 0 ? -1 : anc[anc[b2]];
       }
       anc = nxt;
     }
-    for (int b = 0; b < nb; ++b) if (anc[b] >= 0) { set_err(m, "internal: FK plan incomplete"); return GMR_EINVAL; }
-  }
+    for (int b2 = 0; b2 < n; ++b2) if (anc[b2] >= 0) return false;
+    return true;
+  };
+  std::vector<int> par_full(parent, parent + nb), par_ik(nb_ik);
+  for (int i = 0; i < nb_ik; ++i) par_ik[i] = keep[i] == 0 ? -1 : bmap[parent[keep[i]]];
+  std::vector<u64> fkanc, fkanc_full;
+  int fkrounds = 0, fkrounds_full = 0;
+  if (!fk_plan(par_ik, fkanc, fkrounds) || !fk_plan(par_full, fkanc_full, fkrounds_full)) { set_err(m, "tree too deep"); return GMR_EUNSUPPORTED; }
+  (void)maxdepth;
   // ---- structurally non-zero off-diagonal pairs of H: (i, j) with dof j strictly above dof i ----
   std::vector<unsigned short> hpair;
   for (int i = 0; i < n_act; ++i)
@@ -419,12 +447,12 @@ int build_device_model(gmr_model *m) {
   L.q = o; o += even(nq);
   L.tp = o; o += even(3 * ns);
   L.tq = o; o += 4 * ns;
-  L.bodyc = GMR_IK_STAGE_TREE ? o : -1; o += GMR_IK_STAGE_TREE ? even(gmr::kBodyC * nb) : 0;
+  L.bodyc = GMR_IK_STAGE_TREE ? o : -1; o += GMR_IK_STAGE_TREE ? even(gmr::kBodyC * nb_ik) : 0;
   L.S = o; L.Lb = o; o += std::max(6 * nvp, sq ? 128 : 2 * (nvp + 2));
   L.F = o; o += 6 * nvp;
   L.B = o; L.H = o;
-  const int bt = even(gmr::kBT * ntmax), px = std::max(even(7 * nb), even(gmr::kBT * ncmax));
-  L.xpos = o + bt; L.xquat = L.xpos + even(3 * nb); L.Bc = o + bt;
+  const int bt = even(gmr::kBT * ntmax), px = std::max(even(7 * nb_ik), even(gmr::kBT * ncmax));
+  L.xpos = o + bt; L.xquat = L.xpos + even(3 * nb_ik); L.Bc = o + bt;
   o += std::max(bt + px, (sq ? 1024 : nvp * nvp) + 2);  // + a dummy slot for the unused lanes of the pair rounds
   L.cplan = o;  // composite plan, 16 bytes per (table, pass, quarter-wave); sized once the passes are scheduled (below)
   L.total_doubles = o;
@@ -547,15 +575,26 @@ int build_device_model(gmr_model *m) {
   // ---- pack + upload ----
   std::vector<int> v_parent(parent, parent + nb), v_jtype(jtype, jtype + nb), v_qadr(qadr, qadr + nb);
   std::vector<double> v_bpos(bpos, bpos + 3 * nb), v_bquat(bquat, bquat + 4 * nb), v_axis(axis, axis + 3 * nb), v_qpos0(qpos0, qpos0 + nq);
+  std::vector<int> p_jtype(nb_ik), p_qadr(nb_ik);
+  std::vector<double> p_bpos(3 * nb_ik), p_bquat(4 * nb_ik), p_axis(3 * nb_ik);
+  for (int i = 0; i < nb_ik; ++i) {
+    const int b = keep[i];
+    p_jtype[i] = jtype[b]; p_qadr[i] = qadr[b];
+    for (int c = 0; c < 3; ++c) { p_bpos[3 * i + c] = bpos[3 * b + c]; p_axis[3 * i + c] = axis[3 * b + c]; }
+    for (int c = 0; c < 4; ++c) p_bquat[4 * i + c] = bquat[4 * b + c];
+  }
+  std::vector<int> tbody_ik(tbody), abody_ik(abody);
+  for (int &b : tbody_ik) b = bmap[b] < 0 ? 0 : bmap[b];
+  for (int &b : abody_ik) b = bmap[b];
   std::vector<double> v_sscale(blob_ptr<double>(B, h.off_slot_scale), blob_ptr<double>(B, h.off_slot_scale) + ns);
   std::vector<double> v_spoff(blob_ptr<double>(B, h.off_slot_pos_off), blob_ptr<double>(B, h.off_slot_pos_off) + 3 * ns);
   std::vector<double> v_sroff(blob_ptr<double>(B, h.off_slot_rot_off), blob_ptr<double>(B, h.off_slot_rot_off) + 4 * ns);
   std::vector<int> v_sfoot(blob_ptr<int32_t>(B, h.off_slot_is_foot), blob_ptr<int32_t>(B, h.off_slot_is_foot) + ns);
-  abody.resize(64, 0); akind.resize(64, 0); aqadr.resize(64, 0); alim.resize(64, 0); arange.resize(128, 0.0);
+  abody_ik.resize(64, 0); abody.resize(64, 0); akind.resize(64, 0); aqadr.resize(64, 0); alim.resize(64, 0); arange.resize(128, 0.0);
 
   gmr::DevModel &dm = m->dm;
   dm = gmr::DevModel{};
-  dm.nbody = nb; dm.nq = nq; dm.nv = nv; dm.nslot = ns; dm.root_slot = h.root_slot; dm.n_act = n_act;
+  dm.nbody = nb_ik; dm.nq = nq; dm.nv = nv; dm.nslot = ns; dm.root_slot = h.root_slot; dm.n_act = n_act;
   for (int k = 0; k < 2; ++k) { dm.ntask[k] = h.ntask[k]; dm.use_table[k] = h.use_table[k] && h.ntask[k] > 0; dm.ncomp[k] = ncomp[k]; dm.ncpass[k] = ncpass[k]; }
   dm.npairp = (int)hplan.size() / 2; dm.fkrounds = fkrounds; dm.sq_ok = sq_ok; dm.sq_nlimb = sq_nlimb;
   bool fits = true;
@@ -565,18 +604,40 @@ int build_device_model(gmr_model *m) {
     if (src.size() * sizeof(src[0]) > sizeof(dst)) { fits = false; return; }
     if (!src.empty()) memcpy(&dst[0], src.data(), src.size() * sizeof(src[0]));
   };
-  put(dm.jtype, v_jtype); put(dm.qadr, v_qadr);
-  put(dm.bpos, v_bpos); put(dm.bquat, v_bquat); put(dm.axis, v_axis); put(dm.qpos0, v_qpos0);
+  put(dm.jtype, p_jtype); put(dm.qadr, p_qadr);
+  put(dm.bpos, p_bpos); put(dm.bquat, p_bquat); put(dm.axis, p_axis); put(dm.qpos0, v_qpos0);
   put(dm.sscale, v_sscale); put(dm.spoff, v_spoff); put(dm.sroff, v_sroff); put(dm.sfoot, v_sfoot);
-  put(dm.tbody, tbody); put(dm.tslot, tslot); put(dm.twp, twp); put(dm.twr, twr);
-  put(dm.abody, abody); put(dm.akind, akind); put(dm.aqadr, aqadr); put(dm.alimited, alim);
+  put(dm.tbody, tbody_ik); put(dm.tslot, tslot); put(dm.twp, twp); put(dm.twr, twr);
+  put(dm.abody, abody_ik); put(dm.akind, akind); put(dm.aqadr, aqadr); put(dm.alimited, alim);
   put(dm.arange, arange); put(dm.acomp, acomp);
   put(dm.hplan, hplan); put(dm.fkanc, fkanc); put(dm.comp_plan, comp_plan);
   put(dm.sq_gdof, sq_gdof); put(dm.sq_owner, sq_owner); put(dm.sq_lane_of_dof, sq_lane_of_dof); put(dm.sq_diag, sq_diag);
+  // the evaluation model: same tables, full body tree (gmr_evaluate returns xpos / xquat of every body)
+  std::vector<gmr::DevModel> dm_eval_v(1, dm);
+  {
+    gmr::DevModel &de = dm_eval_v[0];
+    de.nbody = nb; de.fkrounds = fkrounds_full;
+    put(de.jtype, v_jtype); put(de.qadr, v_qadr);
+    put(de.bpos, v_bpos); put(de.bquat, v_bquat); put(de.axis, v_axis);
+    put(de.tbody, tbody); put(de.abody, abody); put(de.fkanc, fkanc_full);
+  }
   if (!fits) { set_err(m, "internal: a model table exceeds its fixed capacity"); return GMR_EUNSUPPORTED; }
+  {  // LDS layout of eval_kernel: state, targets, poses of the full tree
+    gmr::LdsLayout &E = m->lay_eval;
+    E = gmr::LdsLayout{};
+    int oe = 0;
+    E.q = oe; oe += even(nq);
+    E.tp = oe; oe += even(3 * ns);
+    E.tq = oe; oe += 4 * ns;
+    E.xpos = oe; oe += even(3 * nb);
+    E.xquat = oe; oe += 4 * nb;
+    E.total_doubles = oe;
+    m->lds_bytes_eval = oe * (int)sizeof(double);
+  }
 
   Packer P;
   const size_t o_dm = P.add(std::vector<gmr::DevModel>(1));
+  const size_t o_dm_eval = P.add(dm_eval_v);
   const size_t o_parent = P.add(v_parent);
   const size_t o_dofidx = P.add(dofidx), o_src = P.add(src_slot), o_save = P.add(save_slot);
   const size_t o_lpos = P.add(lpos), o_lrot = P.add(lrot), o_jaxis = P.add(jaxis), o_jaxis64 = P.add(jaxis64);
@@ -586,6 +647,7 @@ int build_device_model(gmr_model *m) {
   const uint8_t *D = static_cast<const uint8_t *>(m->dev);
 #define DP(T, off) reinterpret_cast<const T *>(D + (off))
   m->dm_dev = DP(gmr::DevModel, o_dm);
+  m->dm_eval_dev = DP(gmr::DevModel, o_dm_eval);
   gmr::FkTree &fk = m->fk;
   fk.parent = DP(int, o_parent); fk.dofidx = DP(int, o_dofidx); fk.src_slot = DP(int, o_src); fk.save_slot = DP(int, o_save);
   fk.lpos = DP(float, o_lpos); fk.lrot = DP(float, o_lrot); fk.jaxis = DP(float, o_jaxis); fk.jaxis64 = DP(double, o_jaxis64);
@@ -869,7 +931,7 @@ int gmr_evaluate(gmr_model *m, const double *qpos, int64_t n_frames, const void 
     L.hpos = human_pos; L.hquat = human_quat; L.slot_col = static_cast<const int *>(m->ws);
     L.in_f64 = in_dtype == GMR_DTYPE_F64; L.n_cols = n_cols;
   }
-  hipLaunchKernelGGL(gmr::eval_kernel, dim3((unsigned)n_frames), dim3(64), m->lds_bytes, st, m->dm_dev, L, m->lay);
+  hipLaunchKernelGGL(gmr::eval_kernel, dim3((unsigned)n_frames), dim3(64), m->lds_bytes_eval, st, m->dm_eval_dev, L, m->lay_eval);
   HIP_TRY(m, hipGetLastError());
   return GMR_OK;
 }
