@@ -1103,7 +1103,6 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
       const int t_body = m.tbody[trow], t_slot = m.tslot[trow];
       const double t_wp = m.twp[trow], t_wr = m.twr[trow];
       const int a_comp = m.acomp[tab * 64 + arow];
-      const int ncomp = m.ncomp[tab];
 
       double e[6] = {0, 0, 0, 0, 0, 0}, sh = 0.0, ch = 1.0;
       // q has not moved since the FK that closed the previous solve (previous stage or previous frame): the poses in LDS
