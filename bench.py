@@ -189,7 +189,7 @@ def main():
                 "clips_per_gpu": S, "frames_per_clip": T, "frames_per_step": n_frames * world, "parallelism": f"clip-sharded x{world}",
             },
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
-                         "traffic": MEASURED_TRAFFIC_BYTES_PER_FRAME * n_frames, "traffic_source": "profiles/r01_v10_pmc_* scaled to this launch", "kernel": "gmr::ik_kernel<36, true>", "kernel_ms": kern_ms, "bytes_per_frame": bpf},
+                         "traffic": MEASURED_TRAFFIC_BYTES_PER_FRAME * n_frames, "traffic_source": "profiles/r01_v10_pmc_* scaled to this launch", "kernel": f"gmr::ik_kernel<{eng.info.nv_padded}, {'true' if eng.info.reserved[0] else 'false'}>", "kernel_ms": kern_ms, "bytes_per_frame": bpf},
             "valu": {"bound": "fp64-vector", "achieved": ach_tf, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": ach_tf / FP64_VECTOR_PEAK_TF,
                      "flop_per_solve": fsolve, "mean_solves_per_frame": mean_solves,
                      "solves_per_frame_histogram": solves_hist},
