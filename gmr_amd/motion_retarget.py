@@ -239,6 +239,17 @@ class GeneralMotionRetargeting:
             iters = iters.cpu().numpy() if iters is not None else None
         return (out, iters) if return_iters else out
 
+    def fk_batch(self, root_pos, root_rot_xyzw, dof_pos, want_rot: bool = False):
+        """Batched FK in the ``KinematicsModel.forward_kinematics`` convention (float32, xyzw; kinematics_model.py:213-246) on this
+        object's robot: ``root_pos [T,3]``, ``root_rot_xyzw [T,4]``, ``dof_pos [T,ndof]`` -> ``body_pos [T,nbody,3]`` (and
+        ``body_rot [T,nbody,4]`` with ``want_rot``).  numpy in -> numpy out, CUDA tensors in -> CUDA tensors out."""
+        is_np = isinstance(root_pos, np.ndarray)
+        conv = lambda a: (torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a).to(self.device, torch.float32)
+        bp, br = self._engine.fk(conv(root_pos), conv(root_rot_xyzw), conv(dof_pos), want_rot=want_rot)
+        if is_np:
+            bp, br = bp.cpu().numpy(), (br.cpu().numpy() if br is not None else None)
+        return (bp, br) if want_rot else bp
+
     # ------------------------------------------------------------------ helpers mirrored from the reference
     def to_numpy(self, human_data):
         for body_name in human_data.keys():

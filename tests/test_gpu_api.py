@@ -139,6 +139,18 @@ def test_kinematics_model_mirror(golden_dir):
         KinematicsModel(str(params.ROBOT_XML_DICT["unitree_g1"]), device="cpu")
 
 
+def test_fk_batch_on_the_retargeter_matches_kinematics_model(golden_dir):
+    """GeneralMotionRetargeting.fk_batch (batched surface) == the KinematicsModel mirror == the reference golden."""
+    from gmr_amd import GeneralMotionRetargeting as GMR
+    g = GMR("smplx", "unitree_g1")
+    gold = np.load(os.path.join(golden_dir, "fk_unitree_g1.npz"))
+    bp = g.fk_batch(gold["root_pos"], gold["root_rot"], gold["dof_pos"])
+    assert isinstance(bp, np.ndarray) and np.abs(bp - gold["body_pos"]).max() < 2e-6 * max(1.0, np.abs(gold["body_pos"]).max())
+    bp_t, br_t = g.fk_batch(torch.from_numpy(gold["root_pos"]).cuda(), torch.from_numpy(gold["root_rot"]).cuda(),
+                            torch.from_numpy(gold["dof_pos"]).cuda(), want_rot=True)
+    assert bp_t.is_cuda and np.abs(br_t.cpu().numpy() - gold["body_rot"]).max() < 2e-6
+
+
 def test_fk_large_and_min_height():
     from gmr_amd.engine import Engine
     cm = compiled("smplx", "unitree_g1_with_hands")
