@@ -388,10 +388,10 @@ __device__ __forceinline__ void fk_phase(const DevModel &m, const double *bodyc,
 
 // ------------------------------------------------------------------ residual, lane = task
 // e = Log(T_wb^-1 T_wt) in [v; w] order (mink FrameTask.compute_error, via motion_retarget.py:188-200).
-// Returns this lane's |e|^2; e and (sin, cos) of half the rotation angle stay in registers for the assembly.
+// Returns this lane's |e|^2; e and the two scalars (kap, bet) of Jl^-1(e) stay in registers for the assembly.
 // The half-angle sine/cosine are the relative quaternion's own |v| and |w|, so no trig beyond one atan2.
 __device__ __forceinline__ double task_residual(int body, int slot, const double *xpos, const double *xquat, const double *tp,
-                                                const double *tq, double e[6], double &sh, double &ch) {
+                                                const double *tq, double e[6], double &kap, double &bet) {
   const double qb[4] = {xquat[4 * body], xquat[4 * body + 1], xquat[4 * body + 2], xquat[4 * body + 3]};
   const double qt[4] = {tq[4 * slot], tq[4 * slot + 1], tq[4 * slot + 2], tq[4 * slot + 3]};
   const double qc[4] = {qb[0], -qb[1], -qb[2], -qb[3]};
@@ -404,7 +404,7 @@ __device__ __forceinline__ double task_residual(int body, int slot, const double
   mtv(R, d, t);
   // SO3 log, short side (mink.lie.so3.SO3.log)
   const double w = qr[0], n2 = qr[1] * qr[1] + qr[2] * qr[2] + qr[3] * qr[3];
-  double f, c2;
+  double f, c2, sh, ch;  // sh, ch: sine and cosine of half the rotation angle
   if (n2 < kLieEps) {
     const double iw = fast_rcp(w);
     f = 2.0 * iw - 2.0 / 3.0 * n2 * iw * iw * iw;
@@ -418,8 +418,15 @@ __device__ __forceinline__ double task_residual(int body, int slot, const double
   }
   const double om[3] = {f * qr[1], f * qr[2], f * qr[3]};
   const double th2 = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
+  kap = 0.0; bet = 0.0;  // the two scalars of Jl^-1 the task block needs (below mink's threshold it uses the identity)
   if (th2 < kLieEps) c2 = 1.0 / 12.0;
-  else c2 = (1.0 - 0.5 * fast_sqrt(th2) * ch * fast_rcp(sh)) * fast_rcp(th2);
+  else {
+    const double th = fast_sqrt(th2), ith2 = fast_rcp(th2), is = fast_rcp(sh), cot = ch * is;
+    c2 = (1.0 - 0.5 * th * cot) * ith2;
+    const double delta = 0.25 * th * is * is - 0.5 * cot;
+    kap = c2;
+    bet = (c2 - 0.5 * delta * (th * ith2)) * ith2;  // th * ith2 = 1 / th
+  }
   // V^-1 t = t - 1/2 om x t + c2 om x (om x t)
   double a[3], b[3];
   cross(om, t, a);
@@ -434,20 +441,12 @@ __device__ __forceinline__ double task_residual(int body, int slot, const double
 // ------------------------------------------------------------------ task block, lane = task
 // A_t = -[[U, V],[0, U]] with U = Jso3^-1 R', V = Bo R' - U [x_b]x (see header); writes
 // LL = wp^2 U'U, LA = wp^2 U'V, AA = wp^2 V'V + wr^2 U'U, g = A_t' W^2 e  -> out[27]; returns |W e|^2.
-__device__ __forceinline__ double task_block(int body, const double *xpos, const double *xquat, const double e[6], double sh,
-                                             double ch, double wp, double wr, double *out) {
+__device__ __forceinline__ double task_block(int body, const double *xpos, const double *xquat, const double e[6], double kap,
+                                             double bet, double wp, double wr, double *out) {
   const double *u = e, *ph = e + 3;
   const double th2 = ph[0] * ph[0] + ph[1] * ph[1] + ph[2] * ph[2];
   const double pu = ph[0] * u[0] + ph[1] * u[1] + ph[2] * u[2];
-  double kap = 0, bet = 0;
-  const bool small = th2 < kLieEps;  // mink SE3.ljacinv returns the identity below this threshold
-  if (!small) {
-    const double th = fast_sqrt(th2), ith2 = fast_rcp(th2);
-    const double is = fast_rcp(sh), cot = ch * is;
-    kap = (1.0 - 0.5 * th * cot) * ith2;
-    const double delta = 0.25 * th * is * is - 0.5 * cot;
-    bet = (kap - 0.5 * delta * fast_rcp(th)) * ith2;
-  }
+  const bool small = th2 < kLieEps;  // mink SE3.ljacinv returns the identity below this threshold (kap = bet = 0 from the residual)
   // A = I - 1/2 [ph]x + kap (ph ph' - th2 I);  Bo = -1/2 [u]x + kap (ph u' + u ph' - 2 pu I) - 2 bet pu (ph ph' - th2 I)
   double A[9], Bo[9];
   const double k2 = -2.0 * bet * pu;
@@ -528,20 +527,12 @@ __device__ __forceinline__ double quad_get(double v) {
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double pick3(double a, double b, double c, int s) { return s == 0 ? a : (s == 1 ? b : c); }
-__device__ __forceinline__ double task_block_quad(int body, int s, const double *xpos, const double *xquat, const double e[6], double sh,
-                                                  double ch, double wp, double wr, double *out) {
+__device__ __forceinline__ double task_block_quad(int body, int s, const double *xpos, const double *xquat, const double e[6], double kap,
+                                                  double bet, double wp, double wr, double *out) {
   const double *u = e, *ph = e + 3;
   const double th2 = ph[0] * ph[0] + ph[1] * ph[1] + ph[2] * ph[2];
   const double pu = ph[0] * u[0] + ph[1] * u[1] + ph[2] * u[2];
-  double kap = 0, bet = 0;
-  const bool small = th2 < kLieEps;  // mink SE3.ljacinv returns the identity below this threshold
-  if (!small) {
-    const double th = fast_sqrt(th2), ith2 = fast_rcp(th2);
-    const double is = fast_rcp(sh), cot = ch * is;
-    kap = (1.0 - 0.5 * th * cot) * ith2;
-    const double delta = 0.25 * th * is * is - 0.5 * cot;
-    bet = (kap - 0.5 * delta * fast_rcp(th)) * ith2;
-  }
+  const bool small = th2 < kLieEps;  // mink SE3.ljacinv returns the identity below this threshold (kap = bet = 0 from the residual)
   double A[9], Bo[9];
   const double k2 = -2.0 * bet * pu;
 #pragma unroll
@@ -1104,13 +1095,13 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
       const double t_wp = m.twp[trow], t_wr = m.twr[trow];
       const int a_comp = m.acomp[tab * 64 + arow];
 
-      double e[6] = {0, 0, 0, 0, 0, 0}, sh = 0.0, ch = 1.0;
+      double e[6] = {0, 0, 0, 0, 0, 0}, jl_kap = 0.0, jl_bet = 0.0;  // kap, bet of Jl^-1: from the residual to the task block
       // q has not moved since the FK that closed the previous solve (previous stage or previous frame): the poses in LDS
       // are still those of q, so only the very first stage of a work item evaluates FK at entry.
       if (!poses_valid) fk_phase<GMR_IK_STAGE_TREE != 0>(m, bodyc, nbody, fkrounds, lane, q, xpos, xquat);
       poses_valid = true;
       GMR_STAMP(1);
-      double r2 = is_task ? task_residual(t_body, t_slot, xpos, xquat, tp, tq, e, sh, ch) : 0.0;
+      double r2 = is_task ? task_residual(t_body, t_slot, xpos, xquat, tp, tq, e, jl_kap, jl_bet) : 0.0;
       double curr = fast_sqrt(wave_sum(counts ? r2 : 0.0));
       GMR_STAMP(2);
       int num_iter = 0;
@@ -1119,8 +1110,8 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         // ---- per-task 6x6 blocks ----
         double mu = 0.0;
         GMR_DUP(3) if (is_task) {
-          if (quad) mu = task_block_quad(t_body, ts, xpos, xquat, e, sh, ch, t_wp, t_wr, Bt + kBT * tl);
-          else mu = task_block(t_body, xpos, xquat, e, sh, ch, t_wp, t_wr, Bt + kBT * tl);
+          if (quad) mu = task_block_quad(t_body, ts, xpos, xquat, e, jl_kap, jl_bet, t_wp, t_wr, Bt + kBT * tl);
+          else mu = task_block(t_body, xpos, xquat, e, jl_kap, jl_bet, t_wp, t_wr, Bt + kBT * tl);
         }
         const double diag = prm.damping + prm.lm_damping * wave_sum(counts ? mu : 0.0);
         GMR_STAMP(3);
@@ -1294,7 +1285,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         GMR_STAMP(1);
         double next = 0.0;
         GMR_DUP(2) {
-          r2 = is_task ? task_residual(t_body, t_slot, xpos, xquat, tp, tq, e, sh, ch) : 0.0;
+          r2 = is_task ? task_residual(t_body, t_slot, xpos, xquat, tp, tq, e, jl_kap, jl_bet) : 0.0;
           next = fast_sqrt(wave_sum(counts ? r2 : 0.0));
         }
         GMR_STAMP(2);
@@ -1394,8 +1385,8 @@ __global__ void __launch_bounds__(64) eval_kernel(const DevModel *__restrict__ m
     if (m.use_table[tab]) {
       const bool is_task = lane < m.ntask[tab];
       const int trow = tab * GMR_MAX_TASKS + (is_task ? lane : 0);
-      double e[6], sh, ch;
-      err = fast_sqrt(wave_sum(is_task ? task_residual(m.tbody[trow], m.tslot[trow], xpos, xquat, tp, tq, e, sh, ch) : 0.0));
+      double e[6], kap, bet;  // (kap, bet: unused here)
+      err = fast_sqrt(wave_sum(is_task ? task_residual(m.tbody[trow], m.tslot[trow], xpos, xquat, tp, tq, e, kap, bet) : 0.0));
     }
     if (lane == 0) L.err_out[(size_t)f * 2 + tab] = err;
   }
