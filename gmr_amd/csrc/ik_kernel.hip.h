@@ -325,9 +325,12 @@ __device__ __forceinline__ void stage_tree(const DevModel &m, int lane, double *
 }
 // bodyc != nullptr: joint tree staged in LDS (default).  nullptr: re-read from the L2-resident model each call -- the
 // variant for builds that trade LDS for occupancy (GMR_IK_STAGE_TREE=0).
-template <bool STAGED>
-__device__ __forceinline__ void fk_phase(const DevModel &m, const double *bodyc, int nbody, int nrounds, int lane, const double *q,
-                                         double *xpos, double *xquat) {
+// STEP: the root quaternion of q is first advanced by the body-frame rotation w (mj_integratePos for the free joint:
+// q <- normalize(q (x) exp(w)), written back to q[3..6]) -- the half angle |w|/2 shares the one sincos evaluation with the
+// hinges' half angles instead of costing a second, single-lane one in a separate integrate phase.
+template <bool STAGED, bool STEP = false>
+__device__ __forceinline__ void fk_phase(const DevModel &m, const double *bodyc, int nbody, int nrounds, int lane, double *q,
+                                         double *xpos, double *xquat, double wx = 0.0, double wy = 0.0, double wz = 0.0) {
   const bool has = lane < nbody;
   int jtype, qadr;
   u64 ancs;
@@ -351,13 +354,24 @@ __device__ __forceinline__ void fk_phase(const DevModel &m, const double *bodyc,
     for (int i = 0; i < 4; i++) bq[i] = m.bquat[4 * b + i];
   }
   double ql[4] = {bq[0], bq[1], bq[2], bq[3]};
+  const double a2 = STEP ? wx * wx + wy * wy + wz * wz : 0.0, ang = STEP ? fast_sqrt(a2) : 0.0;  // wave-uniform
+  double half = 0.0;
+  if (jtype == GMR_JNT_HINGE) half = 0.5 * q[qadr];
+  else if (STEP && jtype == GMR_JNT_FREE) half = 0.5 * ang;
+  double s, c;
+  sincos_small(half, &s, &c);
   if (jtype == GMR_JNT_FREE) {
     ql[0] = q[3]; ql[1] = q[4]; ql[2] = q[5]; ql[3] = q[6];
+    if (STEP && a2 > 0) {
+      s *= fast_rcp(ang);
+      const double dqt[4] = {c, s * wx, s * wy, s * wz}, q0[4] = {ql[0], ql[1], ql[2], ql[3]};
+      qmul(q0, dqt, ql);
+      qnormalize(ql);
+      q[3] = ql[0]; q[4] = ql[1]; q[5] = ql[2]; q[6] = ql[3];
+    }
     qnormalize(ql);
     pos[0] = q[0]; pos[1] = q[1]; pos[2] = q[2];
   } else if (jtype == GMR_JNT_HINGE) {
-    double s, c;
-    sincos_small(0.5 * q[qadr], &s, &c);
     const double jq[4] = {c, s * ax[0], s * ax[1], s * ax[2]};
     qmul(bq, jq, ql);
   }
@@ -1256,32 +1270,21 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         stamp_acc[15] += (u64)(qit < 0 ? -qit : qit);  // QP iterations (not cycles)
         if constexpr (SQ) stamp_acc[14] += __ballot(sq_own && sq_status != 0) ? 1 : 0;  // solves that end with a non-empty working set
 #endif
-        // ---- integrate (mj_integratePos) ----
-        {
-          const double wx = rdlane(dq, 3), wy = rdlane(dq, 4), wz = rdlane(dq, 5);
-          if (real_row) {
-            if (a_kind < 3) q[a_kind] += dq;
-            else if (a_kind == 6) q[a_qadr] += dq;
-          }
-          if (lane == 0) {
-            const double a2 = wx * wx + wy * wy + wz * wz;
-            if (a2 > 0) {
-              const double ang = fast_sqrt(a2);
-              double s, c;
-              sincos_small(0.5 * ang, &s, &c);
-              s *= fast_rcp(ang);
-              const double dqt[4] = {c, s * wx, s * wy, s * wz}, q0[4] = {q[3], q[4], q[5], q[6]};
-              double o[4];
-              qmul(q0, dqt, o);
-              qnormalize(o);
-              q[3] = o[0]; q[4] = o[1]; q[5] = o[2]; q[6] = o[3];
-            }
-          }
+        // ---- integrate (mj_integratePos): translations and hinges here, the root rotation inside the FK that follows ----
+        const double wx = rdlane(dq, 3), wy = rdlane(dq, 4), wz = rdlane(dq, 5);
+        if (real_row) {
+          if (a_kind < 3) q[a_kind] += dq;
+          else if (a_kind == 6) q[a_qadr] += dq;
         }
         __syncthreads();
         GMR_STAMP(9);
         ++solves;
-        GMR_DUP(1) fk_phase<GMR_IK_STAGE_TREE != 0>(m, bodyc, nbody, fkrounds, lane, q, xpos, xquat);
+#ifdef GMR_DUP_PHASE
+        fk_phase<GMR_IK_STAGE_TREE != 0, true>(m, bodyc, nbody, fkrounds, lane, q, xpos, xquat, wx, wy, wz);
+        if (launder(GMR_DUP_PHASE == 1 ? 1 : 0)) fk_phase<GMR_IK_STAGE_TREE != 0>(m, bodyc, nbody, fkrounds, lane, q, xpos, xquat);
+#else
+        fk_phase<GMR_IK_STAGE_TREE != 0, true>(m, bodyc, nbody, fkrounds, lane, q, xpos, xquat, wx, wy, wz);
+#endif
         GMR_STAMP(1);
         double next = 0.0;
         GMR_DUP(2) {
