@@ -183,6 +183,19 @@ __device__ __forceinline__ double dpp_hop0(double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
+// Two sums at once for the quad layout of the task lanes (lane 4t + 3 carries a_t, lane 4t + 2 carries b_t): stride-4 hops
+// leave the row sums of a in lane 15 and of b in lane 14 of each row; seven hops instead of twelve for two wave_sum.
+__device__ __forceinline__ void quad_sum2(double v, double &sa, double &sb) {
+  v += dpp_hop0<0x114>(v);  // row_shr:4
+  v += dpp_hop0<0x118>(v);  // row_shr:8
+  double w = dpp_hop0<0x111>(v);  // row_shr:1: lane 15 <- lane 14
+  v += dpp_hop0<0x142>(v);
+  w += dpp_hop0<0x142>(w);
+  v += dpp_hop0<0x143>(v);
+  w += dpp_hop0<0x143>(w);
+  sa = rdlane(v, 63);
+  sb = rdlane(w, 63);
+}
 __device__ __forceinline__ double wave_sum(double v) {
   v += dpp_hop0<0x111>(v);  // row_shr:1
   v += dpp_hop0<0x112>(v);  // row_shr:2
@@ -404,18 +417,27 @@ __device__ __forceinline__ void fk_phase(const DevModel &m, const double *bodyc,
 // e = Log(T_wb^-1 T_wt) in [v; w] order (mink FrameTask.compute_error, via motion_retarget.py:188-200).
 // Returns this lane's |e|^2; e and the two scalars (kap, bet) of Jl^-1(e) stay in registers for the assembly.
 // The half-angle sine/cosine are the relative quaternion's own |v| and |w|, so no trig beyond one atan2.
+// rs / xb (optional): row `s` of R(xquat_b) and R' xpos_b, which task_block_quad needs again for the same pose.
 __device__ __forceinline__ double task_residual(int body, int slot, const double *xpos, const double *xquat, const double *tp,
-                                                const double *tq, double e[6], double &kap, double &bet) {
+                                                const double *tq, double e[6], double &kap, double &bet, int s = 0,
+                                                double *rs = nullptr, double *xb = nullptr) {
   const double qb[4] = {xquat[4 * body], xquat[4 * body + 1], xquat[4 * body + 2], xquat[4 * body + 3]};
   const double qt[4] = {tq[4 * slot], tq[4 * slot + 1], tq[4 * slot + 2], tq[4 * slot + 3]};
   const double qc[4] = {qb[0], -qb[1], -qb[2], -qb[3]};
   double qr[4], R[9], d[3], t[3];
   qmul(qc, qt, qr);
   q2mat(qb, R);
-  d[0] = tp[3 * slot] - xpos[3 * body];
-  d[1] = tp[3 * slot + 1] - xpos[3 * body + 1];
-  d[2] = tp[3 * slot + 2] - xpos[3 * body + 2];
+  const double xw[3] = {xpos[3 * body], xpos[3 * body + 1], xpos[3 * body + 2]};
+  d[0] = tp[3 * slot] - xw[0];
+  d[1] = tp[3 * slot + 1] - xw[1];
+  d[2] = tp[3 * slot + 2] - xw[2];
   mtv(R, d, t);
+  if (rs) {
+    mtv(R, xw, xb);
+    rs[0] = s == 0 ? R[0] : (s == 1 ? R[3] : R[6]);
+    rs[1] = s == 0 ? R[1] : (s == 1 ? R[4] : R[7]);
+    rs[2] = s == 0 ? R[2] : (s == 1 ? R[5] : R[8]);
+  }
   // SO3 log, short side (mink.lie.so3.SO3.log)
   const double w = qr[0], n2 = qr[1] * qr[1] + qr[2] * qr[2] + qr[3] * qr[3];
   double f, c2, sh, ch;  // sh, ch: sine and cosine of half the rotation angle
@@ -454,8 +476,8 @@ __device__ __forceinline__ double task_residual(int body, int slot, const double
 
 // ------------------------------------------------------------------ task block, lane = task
 // A_t = -[[U, V],[0, U]] with U = Jso3^-1 R', V = Bo R' - U [x_b]x (see header); writes
-// LL = wp^2 U'U, LA = wp^2 U'V, AA = wp^2 V'V + wr^2 U'U, g = A_t' W^2 e  -> out[27]; returns |W e|^2.
-__device__ __forceinline__ double task_block(int body, const double *xpos, const double *xquat, const double e[6], double kap,
+// LL = wp^2 U'U, LA = wp^2 U'V, AA = wp^2 V'V + wr^2 U'U, g = A_t' W^2 e  -> out[27].
+__device__ __forceinline__ void task_block(int body, const double *xpos, const double *xquat, const double e[6], double kap,
                                              double bet, double wp, double wr, double *out) {
   const double *u = e, *ph = e + 3;
   const double th2 = ph[0] * ph[0] + ph[1] * ph[1] + ph[2] * ph[2];
@@ -517,7 +539,6 @@ __device__ __forceinline__ double task_block(int body, const double *xpos, const
     out[21 + j] = -(U[j] * ev[0] + U[3 + j] * ev[1] + U[6 + j] * ev[2]);
     out[24 + j] = -(V[j] * ev[0] + V[3 + j] * ev[1] + V[6 + j] * ev[2] + U[j] * ew[0] + U[3 + j] * ew[1] + U[6 + j] * ew[2]);
   }
-  return wp2 * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) + wr2 * th2;
 }
 
 // y = B [m; a] for a 6x6 symmetric block [[LL, LA],[LA', AA]] in the layout of kBT
@@ -541,8 +562,8 @@ __device__ __forceinline__ double quad_get(double v) {
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double pick3(double a, double b, double c, int s) { return s == 0 ? a : (s == 1 ? b : c); }
-__device__ __forceinline__ double task_block_quad(int body, int s, const double *xpos, const double *xquat, const double e[6], double kap,
-                                                  double bet, double wp, double wr, double *out) {
+__device__ __forceinline__ void task_block_quad(int s, const double e[6], double kap, double bet, const double rs[3],
+                                                const double xb[3], double wp, double wr, double *out) {
   const double *u = e, *ph = e + 3;
   const double th2 = ph[0] * ph[0] + ph[1] * ph[1] + ph[2] * ph[2];
   const double pu = ph[0] * u[0] + ph[1] * u[1] + ph[2] * u[2];
@@ -561,12 +582,7 @@ __device__ __forceinline__ double task_block_quad(int body, int s, const double 
     A[1] += 0.5 * ph[2]; A[2] -= 0.5 * ph[1]; A[3] -= 0.5 * ph[2]; A[5] += 0.5 * ph[0]; A[6] += 0.5 * ph[1]; A[7] -= 0.5 * ph[0];
     Bo[1] += 0.5 * u[2]; Bo[2] -= 0.5 * u[1]; Bo[3] -= 0.5 * u[2]; Bo[5] += 0.5 * u[0]; Bo[6] += 0.5 * u[1]; Bo[7] -= 0.5 * u[0];
   }
-  const double qb[4] = {xquat[4 * body], xquat[4 * body + 1], xquat[4 * body + 2], xquat[4 * body + 3]};
-  const double xw[3] = {xpos[3 * body], xpos[3 * body + 1], xpos[3 * body + 2]};
-  double R[9], xb[3];
-  q2mat(qb, R);
-  mtv(R, xw, xb);  // body-frame position of the body origin
-  // M = Bo - A [xb]x
+  // M = Bo - A [xb]x, xb the body-frame position of the body origin (from the residual, same pose)
 #pragma unroll
   for (int i = 0; i < 3; i++) {
     const double a0 = A[3 * i], a1 = A[3 * i + 1], a2 = A[3 * i + 2];
@@ -575,7 +591,7 @@ __device__ __forceinline__ double task_block_quad(int body, int s, const double 
     Bo[3 * i + 2] -= a0 * xb[1] - a1 * xb[0];
   }
   // column s of (. R') = (.) times row s of R
-  const double r0 = pick3(R[0], R[3], R[6], s), r1 = pick3(R[1], R[4], R[7], s), r2 = pick3(R[2], R[5], R[8], s);
+  const double r0 = rs[0], r1 = rs[1], r2 = rs[2];
   double uc[3], vc[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) {
@@ -604,7 +620,6 @@ __device__ __forceinline__ double task_block_quad(int body, int s, const double 
     out[21 + s] = -dot(uc, ev);                          // g = A_t' W^2 e = -[U'(wp2 e_v) ; V'(wp2 e_v) + U'(wr2 e_w)]
     out[24 + s] = -(dot(vc, ev) + dot(uc, ew));
   }
-  return wp2 * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) + wr2 * th2;
 }
 
 // ------------------------------------------------------------------ exact box QP, lane = dof (row of H)
@@ -1103,7 +1118,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
       // task lanes: up to 16 tasks get a quad each (lanes 4t .. 4t+2 share the task block, task_block_quad); more than 16 one lane
       const bool quad = nt <= 16;
       const int tl = quad ? lane >> 2 : lane, ts = quad ? lane & 3 : 0;
-      const bool is_task = tl < nt, counts = is_task && ts == 0;  // counts: the one lane of a task that enters wave sums
+      const bool is_task = tl < nt;
       const int trow = tab * GMR_MAX_TASKS + (is_task ? tl : 0);
       const int t_body = m.tbody[trow], t_slot = m.tslot[trow];
       const double t_wp = m.twp[trow], t_wr = m.twr[trow];
@@ -1115,19 +1130,30 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
       if (!poses_valid) fk_phase<GMR_IK_STAGE_TREE != 0>(m, bodyc, nbody, fkrounds, lane, q, xpos, xquat);
       poses_valid = true;
       GMR_STAMP(1);
-      double r2 = is_task ? task_residual(t_body, t_slot, xpos, xquat, tp, tq, e, jl_kap, jl_bet) : 0.0;
-      double curr = fast_sqrt(wave_sum(counts ? r2 : 0.0));
+      double t_rs[3] = {0, 0, 0}, t_xb[3] = {0, 0, 0};  // row ts of R and R' x of the task body, for task_block_quad
+      // |e|^2 (convergence test) and |W e|^2 (LM damping) of all tasks after one residual evaluation
+      auto residual_sums = [&](double &sum_r2, double &sum_mu) {
+        double r2 = 0.0, mu = 0.0;
+        if (is_task) {
+          r2 = task_residual(t_body, t_slot, xpos, xquat, tp, tq, e, jl_kap, jl_bet, ts, t_rs, t_xb);
+          mu = t_wp * t_wp * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) + t_wr * t_wr * (e[3] * e[3] + e[4] * e[4] + e[5] * e[5]);
+        }
+        if (quad) quad_sum2(ts == 3 ? r2 : (ts == 2 ? mu : 0.0), sum_r2, sum_mu);
+        else { sum_r2 = wave_sum(r2); sum_mu = wave_sum(mu); }
+      };
+      double sum_r2, sum_mu;
+      residual_sums(sum_r2, sum_mu);
+      double curr = fast_sqrt(sum_r2);
       GMR_STAMP(2);
       int num_iter = 0;
       bool first = true;
       for (;;) {
         // ---- per-task 6x6 blocks ----
-        double mu = 0.0;
         GMR_DUP(3) if (is_task) {
-          if (quad) mu = task_block_quad(t_body, ts, xpos, xquat, e, jl_kap, jl_bet, t_wp, t_wr, Bt + kBT * tl);
-          else mu = task_block(t_body, xpos, xquat, e, jl_kap, jl_bet, t_wp, t_wr, Bt + kBT * tl);
+          if (quad) task_block_quad(ts, e, jl_kap, jl_bet, t_rs, t_xb, t_wp, t_wr, Bt + kBT * tl);
+          else task_block(t_body, xpos, xquat, e, jl_kap, jl_bet, t_wp, t_wr, Bt + kBT * tl);
         }
-        const double diag = prm.damping + prm.lm_damping * wave_sum(counts ? mu : 0.0);
+        const double diag = prm.damping + prm.lm_damping * sum_mu;
         GMR_STAMP(3);
         // ---- screws S_i (world frame, about the origin) ----
         double Si[6] = {0, 0, 0, 0, 0, 0};
@@ -1185,11 +1211,12 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         }
         __syncthreads();
         GMR_STAMP(5);
-        double ci = 0.0, lo = -1e30, hi = 1e30;
+        double ci = 0.0, lo = -1e30, hi = 1e30, hdiag = 0.0;  // hdiag: S_i . F_i, the undamped diagonal of H
         GMR_DUP(6) if (real_row) {
           const double *B = Bc + kBT * a_comp;
           double Fi[6];
           sym6_mul(B, Si, Si + 3, Fi, Fi + 3);
+          hdiag = Si[0] * Fi[0] + Si[1] * Fi[1] + Si[2] * Fi[2] + Si[3] * Fi[3] + Si[4] * Fi[4] + Si[5] * Fi[5];
 #pragma unroll
           for (int k = 0; k < 6; k++) F[6 * lane + k] = Fi[k];
           ci = Si[0] * B[21] + Si[1] * B[22] + Si[2] * B[23] + Si[3] * B[24] + Si[4] * B[25] + Si[5] * B[26];
@@ -1228,12 +1255,9 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         if constexpr (SQ) {
           // structured layout Hs[col * 64 + lane]: every pair lands in the (at most two) rows that carry it
 #pragma unroll
-          for (int i = 0; i < 16; i++) Hm[i * 64 + lane] = 0.0;  // same wave: LDS keeps program order, no barrier needed
+          for (int i = 0; i < 8; i++) reinterpret_cast<double2 *>(Hm)[i * 64 + lane] = double2{0.0, 0.0};  // same wave: LDS keeps program order
           GMR_DUP(7) h_pairs();
-          if (real_row) {
-            const double *Fi = F + 6 * lane;
-            Hm[sq_mydiag] = Si[0] * Fi[0] + Si[1] * Fi[1] + Si[2] * Fi[2] + Si[3] * Fi[3] + Si[4] * Fi[4] + Si[5] * Fi[5] + diag;
-          }
+          if (real_row) Hm[sq_mydiag] = hdiag + diag;
           if (sq_pad) Hm[(lane & 15) * 64 + lane] = 1.0;
           __syncthreads();
           GMR_STAMP(7);
@@ -1256,10 +1280,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
           for (int i = 0; i < (NVP * NVP + 63) / 64; i++)
             if (i * 64 + lane < NVP * NVP) Hm[i * 64 + lane] = 0.0;  // same wave: LDS keeps program order, no barrier needed
           h_pairs();
-          if (lane < NVP) {
-            const double *Fi = F + 6 * lane;
-            Hm[lane * NVP + lane] = real_row ? Si[0] * Fi[0] + Si[1] * Fi[1] + Si[2] * Fi[2] + Si[3] * Fi[3] + Si[4] * Fi[4] + Si[5] * Fi[5] + diag : 1.0;
-          }
+          if (lane < NVP) Hm[lane * NVP + lane] = real_row ? hdiag + diag : 1.0;
           __syncthreads();
           GMR_STAMP(7);
           qit = box_qp<NVP>(lane, n_act, Hm, lds + lay.Lb, ci, lo, hi, status, dq);
@@ -1288,8 +1309,8 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         GMR_STAMP(1);
         double next = 0.0;
         GMR_DUP(2) {
-          r2 = is_task ? task_residual(t_body, t_slot, xpos, xquat, tp, tq, e, jl_kap, jl_bet) : 0.0;
-          next = fast_sqrt(wave_sum(counts ? r2 : 0.0));
+          residual_sums(sum_r2, sum_mu);
+          next = fast_sqrt(sum_r2);
         }
         GMR_STAMP(2);
         if (!first) ++num_iter;
