@@ -366,27 +366,27 @@ __device__ __forceinline__ void fk_phase(const DevModel &m, const double *bodyc,
 #pragma unroll
     for (int i = 0; i < 4; i++) bq[i] = m.bquat[4 * b + i];
   }
-  double ql[4] = {bq[0], bq[1], bq[2], bq[3]};
+  // One quaternion product for every lane: bq (x) [c, s axis] for a hinge, bq (x) 1 for a body without a joint, and for the
+  // root q_root (x) [c, s w/|w|] (STEP) or q_root (x) 1 -- products with the identity are exact.
+  const bool is_free = jtype == GMR_JNT_FREE;
   const double a2 = STEP ? wx * wx + wy * wy + wz * wz : 0.0, ang = STEP ? fast_sqrt(a2) : 0.0;  // wave-uniform
-  double half = 0.0;
-  if (jtype == GMR_JNT_HINGE) half = 0.5 * q[qadr];
-  else if (STEP && jtype == GMR_JNT_FREE) half = 0.5 * ang;
-  double s, c;
-  sincos_small(half, &s, &c);
-  if (jtype == GMR_JNT_FREE) {
-    ql[0] = q[3]; ql[1] = q[4]; ql[2] = q[5]; ql[3] = q[6];
-    if (STEP && a2 > 0) {
-      s *= fast_rcp(ang);
-      const double dqt[4] = {c, s * wx, s * wy, s * wz}, q0[4] = {ql[0], ql[1], ql[2], ql[3]};
-      qmul(q0, dqt, ql);
-      qnormalize(ql);
-      q[3] = ql[0]; q[4] = ql[1]; q[5] = ql[2]; q[6] = ql[3];
-    }
-    qnormalize(ql);
+  double half = jtype == GMR_JNT_HINGE ? 0.5 * q[qadr] : 0.0;
+  if (is_free) {
+    bq[0] = q[3]; bq[1] = q[4]; bq[2] = q[5]; bq[3] = q[6];
     pos[0] = q[0]; pos[1] = q[1]; pos[2] = q[2];
-  } else if (jtype == GMR_JNT_HINGE) {
-    const double jq[4] = {c, s * ax[0], s * ax[1], s * ax[2]};
-    qmul(bq, jq, ql);
+    if constexpr (STEP) {
+      const double ia = a2 > 0 ? fast_rcp(ang) : 0.0;
+      half = 0.5 * ang;
+      ax[0] = wx * ia; ax[1] = wy * ia; ax[2] = wz * ia;
+    }
+  }
+  double s, c, ql[4];
+  sincos_small(half, &s, &c);
+  const double jq[4] = {c, s * ax[0], s * ax[1], s * ax[2]};
+  qmul(bq, jq, ql);
+  if (is_free) {
+    qnormalize(ql);  // mj_integratePos normalises the advanced quaternion, mj_kinematics the root's (a second pass changes <= 1 ulp)
+    if (STEP && a2 > 0) { q[3] = ql[0]; q[4] = ql[1]; q[5] = ql[2]; q[6] = ql[3]; }
   }
   // lane = body, so "my ancestor's pose" is another lane's registers: fetched through the LDS crossbar (ds_bpermute, no LDS
   // memory, no bank conflicts, no write-then-read round trip per round); only the final poses are stored
@@ -403,9 +403,9 @@ __device__ __forceinline__ void fk_phase(const DevModel &m, const double *bodyc,
       qmul(qa, ql, qo);
       pos[0] = pa[0] + t[0]; pos[1] = pa[1] + t[1]; pos[2] = pa[2] + t[2];
       ql[0] = qo[0]; ql[1] = qo[1]; ql[2] = qo[2]; ql[3] = qo[3];
-      if (r == nr - 1 || ((ancs >> (8 * (r + 1))) & 0xff) == 0xff) qrenorm(ql);  // reached the world frame
     }
   }
+  qrenorm(ql);  // mj_kinematics normalises every body's quaternion; a product of a few unit quaternions needs one Newton step
   if (has) {
     xpos[3 * lane] = pos[0]; xpos[3 * lane + 1] = pos[1]; xpos[3 * lane + 2] = pos[2];
     xquat[4 * lane] = ql[0]; xquat[4 * lane + 1] = ql[1]; xquat[4 * lane + 2] = ql[2]; xquat[4 * lane + 3] = ql[3];
