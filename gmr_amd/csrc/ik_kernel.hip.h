@@ -248,15 +248,15 @@ __device__ __forceinline__ void sincos_small(double x, double *sn, double *cs) {
   *sn = (n & 2) ? -s1 : s1;
   *cs = ((n + 1) & 2) ? -c1 : c1;
 }
-// atan2(y, x) for y >= 0, x >= 0, not both zero (fdlibm atan on [0,1] + reflection)
+// atan2(y, x) for y >= 0, x >= 0, not both zero (fdlibm atan on [0,1] + reflection).  The argument reduction
+// atan(a/b) = atan(c) + atan((a - c b) / (b + c a)), c in {0, 1/2, 1}, is applied to numerator and denominator, so there is one division.
 __device__ __forceinline__ double atan2_pos(double y, double x) {
   const bool swap = y > x;
-  const double a = swap ? x : y, b = swap ? y : x;
-  const double t0 = fast_div(a, b);  // in [0,1]
-  const bool lo = t0 < 0.4375, mid = t0 < 0.6875;
-  const double num = lo ? t0 : (mid ? 2.0 * t0 - 1.0 : t0 - 1.0);
-  const double den = lo ? 1.0 : (mid ? 2.0 + t0 : t0 + 1.0);
-  const double t = lo ? t0 : fast_div(num, den);
+  const double a = swap ? x : y, b = swap ? y : x;  // a / b in [0,1]
+  const bool lo = a < 0.4375 * b, mid = a < 0.6875 * b;
+  const double num = lo ? a : (mid ? 2.0 * a - b : a - b);
+  const double den = lo ? b : (mid ? 2.0 * b + a : a + b);
+  const double t = fast_div(num, den);
   const double z = t * t, w = z * z;
   const double s1 = z * fma(w, fma(w, fma(w, fma(w, fma(w, 1.62858201153657823623e-02, 4.97687799461593236017e-02), 6.66107313738753120669e-02),
                                           9.09088713343650656196e-02), 1.42857142725034663711e-01), 3.33333333333329318027e-01);
@@ -438,30 +438,26 @@ __device__ __forceinline__ double task_residual(int body, int slot, const double
     rs[1] = s == 0 ? R[1] : (s == 1 ? R[4] : R[7]);
     rs[2] = s == 0 ? R[2] : (s == 1 ? R[5] : R[8]);
   }
-  // SO3 log, short side (mink.lie.so3.SO3.log)
+  // SO3 log, short side (mink.lie.so3.SO3.log).  n = sin and |w| = cos of half the rotation angle; the angle itself is
+  // th = |f| n, which saves the square root of |om|^2.
   const double w = qr[0], n2 = qr[1] * qr[1] + qr[2] * qr[2] + qr[3] * qr[3];
-  double f, c2, sh, ch;  // sh, ch: sine and cosine of half the rotation angle
+  const double n = fast_sqrt(n2), aw = fabs(w), in = fast_rcp(n);  // (in is only used where n2 >= kLieEps / 4)
+  double f, c2;
   if (n2 < kLieEps) {
     const double iw = fast_rcp(w);
     f = 2.0 * iw - 2.0 / 3.0 * n2 * iw * iw * iw;
-    sh = fast_sqrt(n2); ch = fabs(w);
-  } else {
-    const double n = fast_sqrt(n2), aw = fabs(w);
-    const double in = fast_rcp(n);
-    if (aw < kLieEps) f = (w > 0 ? 1.0 : -1.0) * M_PI * in;
-    else f = (w < 0 ? -2.0 : 2.0) * atan2_pos(n, aw) * in;
-    sh = n; ch = aw;
-  }
+  } else if (aw < kLieEps) f = (w > 0 ? 1.0 : -1.0) * M_PI * in;
+  else f = (w < 0 ? -2.0 : 2.0) * atan2_pos(n, aw) * in;
   const double om[3] = {f * qr[1], f * qr[2], f * qr[3]};
-  const double th2 = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
+  const double th = fabs(f) * n, th2 = th * th;
   kap = 0.0; bet = 0.0;  // the two scalars of Jl^-1 the task block needs (below mink's threshold it uses the identity)
   if (th2 < kLieEps) c2 = 1.0 / 12.0;
   else {
-    const double th = fast_sqrt(th2), ith2 = fast_rcp(th2), is = fast_rcp(sh), cot = ch * is;
+    const double ith = fast_rcp(th), ith2 = ith * ith, cot = aw * in;
     c2 = (1.0 - 0.5 * th * cot) * ith2;
-    const double delta = 0.25 * th * is * is - 0.5 * cot;
+    const double delta = 0.25 * th * in * in - 0.5 * cot;
     kap = c2;
-    bet = (c2 - 0.5 * delta * (th * ith2)) * ith2;  // th * ith2 = 1 / th
+    bet = (c2 - 0.5 * delta * ith) * ith2;
   }
   // V^-1 t = t - 1/2 om x t + c2 om x (om x t)
   double a[3], b[3];
