@@ -207,26 +207,32 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // ------------------------------------------------------------------ lean float64 math (<= ~1 ulp, no slow paths)
+// The v_rcp_f64 / v_rsq_f64 seeds are good to 4.6e-8 / 5.2e-8 (measured on gfx950, tools/rcp_acc.hip), so a
+// third-order step (error^3) reaches the rounding level in one go, and where a residual correction follows anyway
+// (sqrt, div) a second-order step in front of it is enough.
+__device__ __forceinline__ double rsqrt_step2(double x) {  // ~4e-15
+  const double r = __builtin_amdgcn_rsq(x);
+  return r * fma(-0.5 * x * r, r, 1.5);
+}
 __device__ __forceinline__ double fast_rsqrt(double x) {
-  double r = __builtin_amdgcn_rsq(x);
-  r = r * (1.5 - 0.5 * x * r * r);
-  r = r * (1.5 - 0.5 * x * r * r);
-  return r;
+  const double r = __builtin_amdgcn_rsq(x);
+  const double e = fma(-x * r, r, 1.0);  // 1 - x r^2;  x^-1/2 = r (1 - e)^-1/2 = r (1 + e/2 + 3 e^2 / 8 + ...)
+  return fma(r, e * fma(0.375, e, 0.5), r);
 }
 __device__ __forceinline__ double fast_sqrt(double x) {  // x >= 0
-  const double r = fast_rsqrt(x);
+  const double r = rsqrt_step2(x);
   double s = x * r;
   s = fma(0.5 * r, fma(-s, s, x), s);
   return x > 0.0 ? s : 0.0;
 }
 __device__ __forceinline__ double fast_rcp(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = fma(r, fma(-x, r, 1.0), r);
-  r = fma(r, fma(-x, r, 1.0), r);
-  return r;
+  const double r = __builtin_amdgcn_rcp(x);
+  const double e = fma(-x, r, 1.0);  // 1/x = r / (1 - e) = r (1 + e + e^2 + ...)
+  return fma(r, fma(e, e, e), r);
 }
 __device__ __forceinline__ double fast_div(double a, double b) {
-  const double r = fast_rcp(b);
+  double r = __builtin_amdgcn_rcp(b);
+  r = fma(r, fma(-b, r, 1.0), r);  // ~2e-15, squared by the correction below
   const double q = a * r;
   return fma(r, fma(-q, b, a), q);
 }
