@@ -24,6 +24,7 @@
 using gmr::u64;
 
 struct gmr_model {
+  int hplan_extra_cycles = 0;  // modelled LDS bank-conflict cycles of the H pair plan, per solve (after ordering)
   int device = -1;
   gmr_blob_header h{};
   std::vector<uint8_t> blob;
@@ -544,6 +545,73 @@ int build_device_model(gmr_model *m) {
     while ((hplan.size() / 2) % 64 != 0) {
       hplan.push_back((uint32_t)(Ly.S * 8) | ((uint32_t)(Ly.F * 8) << 16));
       hplan.push_back((uint32_t)((Ly.H + hsize) * 8) | ((uint32_t)((Ly.H + hsize + 1) * 8) << 16));
+    }
+    // Order of the entries = (round, lane) that executes them.  The gathers of S_j / F_i are ds_read_b128 (serviced in four
+    // fixed 16-lane groups, a lane occupying the 16-byte slot (addr / 16) mod 16; equal addresses broadcast) and the two
+    // scatters are ds_write_b64 (16 contiguous lanes per group, unit (addr / 8) mod 16): entries are swapped between positions
+    // while that lowers the number of extra LDS cycles (hill climbing with a fixed seed -- the plan is a pure function of the
+    // model).  Measured on G1: SQ_LDS_BANK_CONFLICT of the H phase.
+    {
+      const int ne = (int)hplan.size() / 2, nr = ne / 64;
+      static const int rgroup[64] = {0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1,
+                                     2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 2, 2, 2, 2, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3};
+      std::vector<int> at(ne);  // position -> entry
+      for (int i = 0; i < ne; ++i) at[i] = i;
+      // extra cycles of one 16-lane group: max over slots of the number of distinct addresses on it, minus one
+      auto extra = [&](const int *pos, int shift, int word, int half) {
+        unsigned addr[16]; int slot[16];
+        for (int l = 0; l < 16; ++l) {
+          const uint32_t wv = hplan[2 * at[pos[l]] + word];
+          addr[l] = half ? (wv >> 16) : (wv & 0xffffu);
+          slot[l] = (int)(addr[l] >> shift) & 15;
+        }
+        int worst = 1;
+        for (int sl = 0; sl < 16; ++sl) {
+          int nd = 0; unsigned seen[16];
+          for (int l = 0; l < 16; ++l) {
+            if (slot[l] != sl) continue;
+            bool dup = false;
+            for (int t = 0; t < nd; ++t) dup = dup || seen[t] == addr[l];
+            if (!dup) seen[nd++] = addr[l];
+          }
+          worst = std::max(worst, nd);
+        }
+        return worst - 1;
+      };
+      auto round_cost = [&](int r) {
+        int c = 0;
+        for (int g = 0; g < 4; ++g) {
+          int rp[16], wp[16], n = 0;
+          for (int l = 0; l < 64; ++l) if (rgroup[l] == g) rp[n++] = 64 * r + l;
+          for (int l = 0; l < 16; ++l) wp[l] = 64 * r + 16 * g + l;
+          c += 3 * (extra(rp, 4, 0, 0) + extra(rp, 4, 0, 1));  // three b128 reads each of S_j and F_i
+          c += extra(wp, 3, 1, 0) + extra(wp, 3, 1, 1);
+        }
+        return c;
+      };
+      std::vector<int> rc(nr);
+      for (int r = 0; r < nr; ++r) rc[r] = round_cost(r);
+      int total0 = 0;
+      for (int r = 0; r < nr; ++r) total0 += rc[r];
+      uint64_t rng = 0x9E3779B97F4A7C15ull;
+      auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (uint32_t)(rng >> 32); };
+      for (int iter = 0; iter < 40000 && nr > 0; ++iter) {
+        const int a = (int)(next() % (uint32_t)ne), b = (int)(next() % (uint32_t)ne);
+        if (a == b) continue;
+        const int ra = a / 64, rb = b / 64;
+        std::swap(at[a], at[b]);
+        const int na = round_cost(ra), nb2 = ra == rb ? na : round_cost(rb);
+        const int before = rc[ra] + (ra == rb ? 0 : rc[rb]), after = na + (ra == rb ? 0 : nb2);
+        if (after <= before) { rc[ra] = na; rc[rb] = nb2; }
+        else std::swap(at[a], at[b]);
+      }
+      std::vector<uint32_t> ordered(hplan.size());
+      for (int i = 0; i < ne; ++i) { ordered[2 * i] = hplan[2 * at[i]]; ordered[2 * i + 1] = hplan[2 * at[i] + 1]; }
+      int total = 0;
+      for (int r = 0; r < nr; ++r) total += rc[r];
+      m->hplan_extra_cycles = total;
+      if (getenv("GMR_DEBUG_PLAN")) fprintf(stderr, "gmr: H pair plan %d entries, modelled conflict cycles per solve %d -> %d\n", ne, total0, total);
+      hplan.swap(ordered);
     }
   }
   // ---- FK (KinematicsModel convention) tables and branch-slot plan ----
