@@ -70,7 +70,11 @@ typedef unsigned long long u64;
 #define GMR_IK_WAVES_PER_SIMD 2
 #endif
 
-constexpr int kBT = 28;  // doubles per task block: LL(6) LA(9) AA(6) g(6) + 1 pad (never read), stored "by column": element 3k + s, s = 0..2,
+// Doubles per task / composite block: LL(6) LA(9) AA(6) g(6) = 27 used, the block sums move 28 (14 lanes x 16 bytes), and the
+// stride is 30 = 15 sixteen-byte slots, odd, so that the blocks of different composites start on different LDS slots: the F
+// phase (every dof lane reads element c of ITS composite) then has no bank conflicts (stride 28 = 14 slots: 91 extra LDS
+// cycles per solve on G1).  Stored "by column": element 3k + s, s = 0..2,
+constexpr int kBT = 30, kBTLanes = 14;
 // k: 0 LL(s,s)  1 LL(s,s+1)  2..4 LA(s,s), LA(s,s+1), LA(s,s+2)  5 AA(s,s)  6 AA(s,s+1)  7 gl_s  8 ga_s   (indices mod 3)
 // -- the order in which three lanes per task (one per column s) produce it in task_block_quad
 __host__ __device__ constexpr int bt_ll(int i, int j) { return i == j ? i : ((j - i + 3) % 3 == 1 ? 3 + i : 3 + j); }
@@ -145,6 +149,13 @@ __device__ __forceinline__ int launder_uniform(int v) {
   asm volatile("" : "+s"(v));
   return v;
 }
+
+// LDS reads of the right width.  Left alone, the compiler pairs neighbouring 8-byte LDS reads into ds_read2_b64, which the
+// LDS serves at half the rate of ds_read_b64 / ds_read_b128 (8 cycles per wave for 16 bytes per lane against 2 for 8 and 4 for
+// 16, MI355X_MICROARCH "LDS").  lds1: one ds_read_b64 that is never paired (volatile); lds2: one ds_read_b128 (16-byte aligned).
+typedef const volatile __attribute__((address_space(3))) double lds_volatile_double;
+__device__ __forceinline__ double lds1(const double *p) { return *(lds_volatile_double *)p; }  // p must point into LDS
+__device__ __forceinline__ double2 lds2(const double *p) { return *reinterpret_cast<const double2 *>(__builtin_assume_aligned(p, 16)); }
 
 // ------------------------------------------------------------------ wave helpers (wave = 64)
 __device__ __forceinline__ double rdlane(double v, int lane) {  // lane: wave-uniform
@@ -861,7 +872,7 @@ __device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool 
     lane = launder(lane);
     double R[16];
 #pragma unroll
-    for (int b = 0; b < 16; b++) R[b] = Hs[b * 64 + lane];
+    for (int b = 0; b < 16; b++) R[b] = lds1(Hs + b * 64 + lane);
     double bb = (owner ? -ci : 0.0);
     if (__ballot(owner && status != 0)) {  // wave-uniform, ~4 % of the solves: a working set exists
       // effective status / value of every structured row (copies follow their owner, padding is pinned at 0); rows / columns
@@ -1194,7 +1205,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
                       // destination; no masks, no selects.  Same wave, so LDS program order makes a pass see the previous one's
                       // writes without a barrier.
           const int np = m.ncpass[tab];
-          if ((lane & 15) < kBT / 2) {
+          if ((lane & 15) < kBTLanes) {
             char *lb = reinterpret_cast<char *>(lds);
             const unsigned el16 = 16u * (lane & 15);
             const uint4 *plan = reinterpret_cast<const uint4 *>(lds + lay.cplan) + (tab ? 4 * m.ncpass[0] : 0) + (lane >> 4);
@@ -1207,7 +1218,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
               double2 sum;
               sum.x = (v0.x + v1.x) + (v2.x + v3.x);
               sum.y = (v0.y + v1.y) + (v2.y + v3.y);
-              *reinterpret_cast<double2 *>(lb + (cur.z + el16)) = sum;
+              *reinterpret_cast<double2 *>(lb + ((cur.z | cur.w) + el16)) = sum;  // (w is 0: keeps the plan read a b128, not a half-rate b96)
             }
           }
         }
@@ -1215,7 +1226,12 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         GMR_STAMP(5);
         double ci = 0.0, lo = -1e30, hi = 1e30, hdiag = 0.0;  // hdiag: S_i . F_i, the undamped diagonal of H
         GMR_DUP(6) if (real_row) {
-          const double *B = Bc + kBT * a_comp;
+          double B[kBTLanes * 2];  // the composite block, seven b128 reads per half
+#pragma unroll
+          for (int c = 0; c < kBTLanes; c++) {
+            const double2 v = lds2(Bc + kBT * a_comp + 2 * c);
+            B[2 * c] = v.x; B[2 * c + 1] = v.y;
+          }
           double Fi[6];
           sym6_mul(B, Si, Si + 3, Fi, Fi + 3);
           hdiag = Si[0] * Fi[0] + Si[1] * Fi[1] + Si[2] * Fi[2] + Si[3] * Fi[3] + Si[4] * Fi[4] + Si[5] * Fi[5];
