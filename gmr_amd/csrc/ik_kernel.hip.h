@@ -587,46 +587,38 @@ __device__ __forceinline__ void task_block_quad(int s, const double e[6], double
   const double *u = e, *ph = e + 3;
   const double th2 = ph[0] * ph[0] + ph[1] * ph[1] + ph[2] * ph[2];
   const double pu = ph[0] * u[0] + ph[1] * u[1] + ph[2] * u[2];
-  const bool small = th2 < kLieEps;  // mink SE3.ljacinv returns the identity below this threshold (kap = bet = 0 from the residual)
-  double A[9], Bo[9];
-  const double k2 = -2.0 * bet * pu;
+  // mink SE3.ljacinv returns the identity below its threshold: kap = bet = 0 from the residual, and the two skew terms go too
+  const double hs = th2 < kLieEps ? 0.0 : 0.5;
+  // A = I - 1/2 [ph]x + kap (ph ph' - th2 I);  Bo = -1/2 [u]x + kap (ph u' + u ph' - 2 pu I) + k2 (ph ph' - th2 I), k2 = -2 bet pu.
+  // Only column s of U = A R' and of V = (Bo - A [xb]x) R' is needed here, i.e. A r, Bo r and A (xb x r) with r = row s of R
+  // (xb = R' x, the body-frame position of the body origin, and r come from the residual of the same pose): the matrices are
+  // applied in vector form, never built.
+  const double k2 = -2.0 * bet * pu, a0 = 1.0 - kap * th2;
+  auto dot = [](const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+  auto applyA = [&](const double v[3], double pv, double o[3]) {  // A v, pv = ph . v
+    double c[3];
+    cross(ph, v, c);
+    const double bv = kap * pv;
 #pragma unroll
-  for (int i = 0; i < 3; i++)
+    for (int i = 0; i < 3; i++) o[i] = a0 * v[i] - hs * c[i] + bv * ph[i];
+  };
+  const double pr = dot(ph, rs), ur = dot(u, rs);
+  double uc[3], vc[3], w[3], aw[3], cu[3];
+  applyA(rs, pr, uc);
+  cross(xb, rs, w);
+  applyA(w, dot(ph, w), aw);
+  cross(u, rs, cu);
+  const double c_ph = kap * ur + k2 * pr, c_u = kap * pr, c_r = -2.0 * kap * pu - k2 * th2;
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
-      const double pp = ph[i] * ph[j] - (i == j ? th2 : 0.0);
-      A[3 * i + j] = (i == j ? 1.0 : 0.0) + kap * pp;
-      Bo[3 * i + j] = small ? 0.0 : kap * (ph[i] * u[j] + u[i] * ph[j] - (i == j ? 2.0 * pu : 0.0)) + k2 * pp;
-    }
-  if (!small) {
-    A[1] += 0.5 * ph[2]; A[2] -= 0.5 * ph[1]; A[3] -= 0.5 * ph[2]; A[5] += 0.5 * ph[0]; A[6] += 0.5 * ph[1]; A[7] -= 0.5 * ph[0];
-    Bo[1] += 0.5 * u[2]; Bo[2] -= 0.5 * u[1]; Bo[3] -= 0.5 * u[2]; Bo[5] += 0.5 * u[0]; Bo[6] += 0.5 * u[1]; Bo[7] -= 0.5 * u[0];
-  }
-  // M = Bo - A [xb]x, xb the body-frame position of the body origin (from the residual, same pose)
-#pragma unroll
-  for (int i = 0; i < 3; i++) {
-    const double a0 = A[3 * i], a1 = A[3 * i + 1], a2 = A[3 * i + 2];
-    Bo[3 * i] -= a1 * xb[2] - a2 * xb[1];
-    Bo[3 * i + 1] -= a2 * xb[0] - a0 * xb[2];
-    Bo[3 * i + 2] -= a0 * xb[1] - a1 * xb[0];
-  }
-  // column s of (. R') = (.) times row s of R
-  const double r0 = rs[0], r1 = rs[1], r2 = rs[2];
-  double uc[3], vc[3];
-#pragma unroll
-  for (int i = 0; i < 3; i++) {
-    uc[i] = A[3 * i] * r0 + A[3 * i + 1] * r1 + A[3 * i + 2] * r2;
-    vc[i] = Bo[3 * i] * r0 + Bo[3 * i + 1] * r1 + Bo[3 * i + 2] * r2;
-  }
+  for (int i = 0; i < 3; i++) vc[i] = c_ph * ph[i] + c_u * u[i] + c_r * rs[i] - hs * cu[i] - aw[i];
   // columns s+1 and s+2 from the quad neighbours (quad_perm [1,2,0,3] = 0xC9 and [2,0,1,3] = 0xD2)
-  double u1[3], v1[3], u2[3], v2[3];
+  double u1[3], v1[3], v2[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) {
     u1[i] = quad_get<0xC9>(uc[i]); v1[i] = quad_get<0xC9>(vc[i]);
-    u2[i] = quad_get<0xD2>(uc[i]); v2[i] = quad_get<0xD2>(vc[i]);
+    v2[i] = quad_get<0xD2>(vc[i]);
   }
   const double wp2 = wp * wp, wr2 = wr * wr;
-  auto dot = [](const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
   const double uu = dot(uc, uc), uu1 = dot(uc, u1);
   const double ev[3] = {wp2 * e[0], wp2 * e[1], wp2 * e[2]}, ew[3] = {wr2 * e[3], wr2 * e[4], wr2 * e[5]};
   if (s < 3) {
@@ -907,6 +899,7 @@ __device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool 
     // and narrows EXEC to a > k for its updates and for everything after it, so a step costs one compare instead of two
     // masked regions; rows above the pivot simply stay switched off until the back-substitution.  `myinvd` is overwritten by
     // every step a row still takes part in, the last of which is its own.
+    int ak = a;
     auto elim = [&](auto &&self, auto K) -> void {
       constexpr int k = K;
       if constexpr (k >= 6 && k <= 10) {
@@ -927,7 +920,8 @@ __device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool 
       const double u = ck * invd;
       R[k] = 0.0;  // dead from here (also the pivot's own diagonal): the back-substitution needs no triangle mask
       if constexpr (k < 15) {
-        if (launder(a) > k) {  // rows below the pivot (their lanes are exactly the sources of the broadcasts inside)
+        ak = launder(ak);  // (in place: no copy; keeps the sixteen compares from being hoisted into long-lived lane masks)
+        if (ak > k) {  // rows below the pivot (their lanes are exactly the sources of the broadcasts inside)
           static_for<k + 1, 16>([&](auto J) {
             constexpr int jj = J;
             R[jj] -= u * group_bcast<jj>(ck);
@@ -1194,9 +1188,8 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
           const int kk = is_trans ? a_kind : a_kind - 3;
 #pragma unroll
           for (int i = 0; i < 3; i++) a_axis[i] = is_root ? (kk == i ? 1.0 : 0.0) : a_axis[i];
-          double R[9], ax[3], mo[3];
-          q2mat(qb, R);
-          mv(R, a_axis, ax);
+          double ax[3], mo[3];
+          qrot(qb, a_axis, ax);  // R(q) a without forming R
           cross(xb, ax, mo);
 #pragma unroll
           for (int i = 0; i < 3; i++) { Si[i] = is_trans ? a_axis[i] : mo[i]; Si[3 + i] = is_trans ? 0.0 : ax[i]; }
