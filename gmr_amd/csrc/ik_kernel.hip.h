@@ -272,24 +272,19 @@ __device__ __forceinline__ void sincos_small(double x, double *sn, double *cs) {
   *sn = (n & 2) ? -s1 : s1;
   *cs = ((n + 1) & 2) ? -c1 : c1;
 }
-// atan2(y, x) for y >= 0, x >= 0, not both zero (fdlibm atan on [0,1] + reflection).  The argument reduction
-// atan(a/b) = atan(c) + atan((a - c b) / (b + c a)), c in {0, 1/2, 1}, is applied to numerator and denominator, so there is one division.
-__device__ __forceinline__ double atan2_pos(double y, double x) {
-  const bool swap = y > x;
-  const double a = swap ? x : y, b = swap ? y : x;  // a / b in [0,1]
-  const bool lo = a < 0.4375 * b, mid = a < 0.6875 * b;
-  const double num = lo ? a : (mid ? 2.0 * a - b : a - b);
-  const double den = lo ? b : (mid ? 2.0 * b + a : a + b);
-  const double t = fast_div(num, den);
+// atan2(y, x) for y = sin(phi) >= 0, x = cos(phi) >= 0 of ONE angle (x^2 + y^2 = 1: the scalar and vector norms of a unit
+// quaternion), phi in [0, pi/2].  Two half-angle steps need no range selection at all: cos(phi/2) = sqrt((1 + x) / 2),
+// tan(phi/4) = sin(phi/2) / (1 + cos(phi/2)) = y / (2 c (1 + c)) <= tan(pi/8) = 0.4142, inside the interval where fdlibm's
+// atan kernel is used without argument reduction; phi = 4 atan(tan(phi/4)).
+__device__ __forceinline__ double atan2_unit(double y, double x) {
+  const double c = fast_sqrt(fma(0.5, x, 0.5));
+  const double t = y * fast_rcp(2.0 * c * (1.0 + c));
   const double z = t * t, w = z * z;
   const double s1 = z * fma(w, fma(w, fma(w, fma(w, fma(w, kc(1.62858201153657823623e-02), kc(4.97687799461593236017e-02)), kc(6.66107313738753120669e-02)),
                                           kc(9.09088713343650656196e-02)), kc(1.42857142725034663711e-01)), kc(3.33333333333329318027e-01));
   const double s2 = w * fma(w, fma(w, fma(w, fma(w, kc(-3.65315727442169155270e-02), kc(-5.83357013379057348645e-02)), kc(-7.69187620504482999495e-02)),
                                    kc(-1.11111104054623557880e-01)), kc(-1.99999999998764832476e-01));
-  const double hi = lo ? 0.0 : (mid ? 4.63647609000806093515e-01 : 7.85398163397448278999e-01);
-  const double lw = lo ? 0.0 : (mid ? 2.26987774529616870924e-17 : 3.06161699786838301793e-17);
-  const double r = hi - ((t * (s1 + s2) - lw) - t);
-  return swap ? 1.57079632679489655800e+00 - r + 6.12323399573676603587e-17 : r;
+  return 4.0 * (t - t * (s1 + s2));
 }
 
 // ------------------------------------------------------------------ quaternion / matrix helpers (wxyz)
@@ -471,7 +466,7 @@ __device__ __forceinline__ double task_residual(int body, int slot, const double
     const double iw = fast_rcp(w);
     f = 2.0 * iw - 2.0 / 3.0 * n2 * iw * iw * iw;
   } else if (aw < kLieEps) f = (w > 0 ? 1.0 : -1.0) * M_PI * in;
-  else f = (w < 0 ? -2.0 : 2.0) * atan2_pos(n, aw) * in;
+  else f = (w < 0 ? -2.0 : 2.0) * atan2_unit(n, aw) * in;
   const double om[3] = {f * qr[1], f * qr[2], f * qr[3]};
   const double th = fabs(f) * n, th2 = th * th;
   kap = 0.0; bet = 0.0;  // the two scalars of Jl^-1 the task block needs (below mink's threshold it uses the identity)
