@@ -304,14 +304,15 @@ __device__ __forceinline__ void qrenorm(double q[4]) {
   const double r = fma(-0.5, q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3], 1.5);
   q[0] *= r; q[1] *= r; q[2] *= r; q[3] *= r;
 }
-__device__ __forceinline__ void q2mat(const double q[4], double R[9]) {  // mju_quat2Mat
-  double q00 = q[0] * q[0], q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3];
-  double q11 = q[1] * q[1], q12 = q[1] * q[2], q13 = q[1] * q[3];
-  double q22 = q[2] * q[2], q23 = q[2] * q[3], q33 = q[3] * q[3];
-  R[0] = q00 + q11 - q22 - q33; R[4] = q00 - q11 + q22 - q33; R[8] = q00 - q11 - q22 + q33;
-  R[1] = 2 * (q12 - q03); R[2] = 2 * (q13 + q02);
-  R[3] = 2 * (q12 + q03); R[5] = 2 * (q23 - q01);
-  R[6] = 2 * (q13 - q02); R[7] = 2 * (q23 + q01);
+__device__ __forceinline__ void q2mat(const double q[4], double R[9]) {  // mju_quat2Mat for a unit quaternion
+  // diagonal as 1 - 2 (y^2 + z^2) (= w^2 + x^2 - y^2 - z^2 when |q| = 1), doubled components shared: 21 operations
+  const double x2 = q[1] + q[1], y2 = q[2] + q[2], z2 = q[3] + q[3];
+  const double xx = x2 * q[1], yy = y2 * q[2], zz = z2 * q[3];
+  const double wx = x2 * q[0], wy = y2 * q[0], wz = z2 * q[0];
+  R[0] = (1.0 - yy) - zz; R[4] = (1.0 - xx) - zz; R[8] = (1.0 - xx) - yy;
+  R[1] = fma(x2, q[2], -wz); R[3] = fma(x2, q[2], wz);
+  R[2] = fma(x2, q[3], wy); R[6] = fma(x2, q[3], -wy);
+  R[5] = fma(y2, q[3], -wx); R[7] = fma(y2, q[3], wx);
 }
 __device__ __forceinline__ void mv(const double R[9], const double v[3], double o[3]) {
   o[0] = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
@@ -338,10 +339,11 @@ __device__ __forceinline__ void cross(const double a[3], const double b[3], doub
 // fetched from its lane's registers by ds_bpermute.
 // The joint tree (per-body pos / quat / axis / joint type / ancestor plan) is staged in LDS once per wavefront.
 __device__ __forceinline__ void qrot(const double q[4], const double v[3], double o[3]) {  // R(q) v, q unit
-  const double tx = 2.0 * (q[2] * v[2] - q[3] * v[1]), ty = 2.0 * (q[3] * v[0] - q[1] * v[2]), tz = 2.0 * (q[1] * v[1] - q[2] * v[0]);
-  o[0] = v[0] + q[0] * tx + (q[2] * tz - q[3] * ty);
-  o[1] = v[1] + q[0] * ty + (q[3] * tx - q[1] * tz);
-  o[2] = v[2] + q[0] * tz + (q[1] * ty - q[2] * tx);
+  // v + 2 (w c + qv x c), c = qv x v: 18 operations
+  const double cx = q[2] * v[2] - q[3] * v[1], cy = q[3] * v[0] - q[1] * v[2], cz = q[1] * v[1] - q[2] * v[0];
+  o[0] = fma(2.0, q[0] * cx + (q[2] * cz - q[3] * cy), v[0]);
+  o[1] = fma(2.0, q[0] * cy + (q[3] * cx - q[1] * cz), v[1]);
+  o[2] = fma(2.0, q[0] * cz + (q[1] * cy - q[2] * cx), v[2]);
 }
 constexpr int kBodyC = 11;  // doubles per body in the LDS-staged joint tree: pos(3) quat(4) axis(3) {fkanc(6 bytes), jtype, qadr}
 // Stage this lane's body of the joint tree into LDS (once per wavefront).
