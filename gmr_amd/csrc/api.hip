@@ -443,7 +443,7 @@ int build_device_model(gmr_model *m) {
   auto even = [](int x) { return (x + 1) & ~1; };
   int o = 0;
   L.zero = o; o += gmr::kBT;  // a block of zeros: the absent sources of the composite plan (never aliased)
-  const int npairp_host = ((int)hpair.size() + 63) / 64 * 64;
+  const int npairp_host = ((int)hpair.size() + 127) / 128 * 128;
   L.hplan = o; o += npairp_host;  // H pair plan, 8 bytes per entry (staged once per wavefront)
   L.q = o; o += even(nq);
   L.tp = o; o += even(3 * ns);
@@ -542,7 +542,7 @@ int build_device_model(gmr_model *m) {
       hplan.push_back((uint32_t)((Ly.S + 6 * j) * 8) | ((uint32_t)((Ly.F + 6 * i) * 8) << 16));
       hplan.push_back((uint32_t)((Ly.H + (int)d0) * 8) | ((uint32_t)((Ly.H + (int)d1) * 8) << 16));
     }
-    while ((hplan.size() / 2) % 64 != 0) {
+    while ((hplan.size() / 2) % 128 != 0) {
       hplan.push_back((uint32_t)(Ly.S * 8) | ((uint32_t)(Ly.F * 8) << 16));
       hplan.push_back((uint32_t)((Ly.H + hsize) * 8) | ((uint32_t)((Ly.H + hsize + 1) * 8) << 16));
     }

@@ -86,11 +86,11 @@ constexpr double kLieEps = 1e-10;  // mink.lie.utils.get_epsilon(float64)
 // A compiled model as the kernels see it: ONE struct of fixed-capacity arrays in device memory (filled by api.hip), reached
 // through a single kernel-argument pointer.  Every table is base + compile-time offset, so the model costs two SGPRs instead
 // of two per table (with ~45 tables passed by value the kernel spilled hundreds of SGPRs into VGPR lanes).
-constexpr int kMaxPairsPadded = (GMR_MAX_BODIES * (GMR_MAX_BODIES - 1) / 2 + 63) / 64 * 64;
+constexpr int kMaxPairsPadded = (GMR_MAX_BODIES * (GMR_MAX_BODIES - 1) / 2 + 127) / 128 * 128;
 struct DevModel {
   int nbody, nq, nv, nslot, root_slot, n_act, pad0, pad1;
   int ntask[2], use_table[2], ncomp[2], ncpass[2];  // ncpass: composite passes per table
-  int npairp, fkrounds, sq_ok, sq_nlimb;              // npairp: entries of hplan (a multiple of 64)
+  int npairp, fkrounds, sq_ok, sq_nlimb;              // npairp: entries of hplan (a multiple of 128)
   // per active dof [64]
   int abody[64], akind[64], aqadr[64], alimited[64];  // akind: 0..2 root translation, 3..5 root rotation, 6 hinge
   double arange[128];                                 // [64][2]
@@ -1015,7 +1015,6 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
   const int a_body = m.abody[arow], a_kind = real_row ? m.akind[arow] : -1, a_qadr = m.aqadr[arow], a_lim = real_row ? m.alimited[arow] : 0;
   const bool is_slot = lane < nslot;
   const int s_col = L.slot_col[is_slot ? lane : 0], root_col = L.slot_col[root_slot];
-  constexpr int kPairRounds = (NVP * (NVP - 1) / 2 + 63) / 64;
 
   // structured QP: this lane's row in the 4 x 16 layout
   const int sq_g = SQ ? (int)m.sq_gdof[lane] : -1;
@@ -1248,21 +1247,26 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         // every structurally non-zero off-diagonal pair (i below j): H[i][j] = H[j][i] = S_j . F_i, spread over all lanes by a
         // host-made plan of LDS byte offsets (padding entries land in the dummy slots)
         auto h_pairs = [&]() {
+          // Two rounds of 64 pairs per iteration (the plan is padded to a multiple of 128): the twelve gathers of an iteration are
+          // in flight together and its two dot-product chains interleave, and the next iteration's plan entries are read while
+          // this one computes -- per-round branches used to serialise read -> wait -> chain -> write five times over.
           char *lb = reinterpret_cast<char *>(lds);
           const uint2 *hp = reinterpret_cast<const uint2 *>(lds + lay.hplan) + lane;
-          uint2 pl[kPairRounds];
-#pragma unroll
-          for (int r = 0; r < kPairRounds; r++)
-            if (64 * r < npairp) pl[r] = hp[64 * r];  // wave-uniform guard
-#pragma unroll
-          for (int r = 0; r < kPairRounds; r++) {
-            if (64 * r < npairp) {
-              const double2 *Sj = reinterpret_cast<const double2 *>(lb + (pl[r].x & 0xffffu)), *Fi = reinterpret_cast<const double2 *>(lb + (pl[r].x >> 16));
-              const double2 s0 = Sj[0], s1 = Sj[1], s2 = Sj[2], f0 = Fi[0], f1 = Fi[1], f2 = Fi[2];
-              const double d = s0.x * f0.x + s0.y * f0.y + s1.x * f1.x + s1.y * f1.y + s2.x * f2.x + s2.y * f2.y;
-              *reinterpret_cast<double *>(lb + (pl[r].y & 0xffffu)) = d;
-              *reinterpret_cast<double *>(lb + (pl[r].y >> 16)) = d;
-            }
+          const int n2 = npairp >> 7;
+          uint2 pa = hp[0], pb = hp[64];
+          for (int it = 0; it < n2; ++it) {
+            const uint2 ca = pa, cb = pb;
+            if (it + 1 < n2) { pa = hp[128 * (it + 1)]; pb = hp[128 * (it + 1) + 64]; }
+            const double2 *Sa = reinterpret_cast<const double2 *>(lb + (ca.x & 0xffffu)), *Fa = reinterpret_cast<const double2 *>(lb + (ca.x >> 16));
+            const double2 *Sb = reinterpret_cast<const double2 *>(lb + (cb.x & 0xffffu)), *Fb = reinterpret_cast<const double2 *>(lb + (cb.x >> 16));
+            const double2 a0 = Sa[0], a1 = Sa[1], a2 = Sa[2], f0 = Fa[0], f1 = Fa[1], f2 = Fa[2];
+            const double2 b0 = Sb[0], b1 = Sb[1], b2 = Sb[2], g0 = Fb[0], g1 = Fb[1], g2 = Fb[2];
+            const double da = a0.x * f0.x + a0.y * f0.y + a1.x * f1.x + a1.y * f1.y + a2.x * f2.x + a2.y * f2.y;
+            const double db = b0.x * g0.x + b0.y * g0.y + b1.x * g1.x + b1.y * g1.y + b2.x * g2.x + b2.y * g2.y;
+            *reinterpret_cast<double *>(lb + (ca.y & 0xffffu)) = da;
+            *reinterpret_cast<double *>(lb + (ca.y >> 16)) = da;
+            *reinterpret_cast<double *>(lb + (cb.y & 0xffffu)) = db;
+            *reinterpret_cast<double *>(lb + (cb.y >> 16)) = db;
           }
         };
         double dq;
