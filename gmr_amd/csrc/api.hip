@@ -469,10 +469,31 @@ int build_device_model(gmr_model *m) {
     // src / dst are block ids: task t -> t, composite c -> 64 + c;  deps: entries that must have run in an earlier pass
     std::vector<Entry> ent;
     std::vector<int> last_entry_of_comp(ncomp[k], -1);
+    // Shallow plan: a composite of ONE task is that task's block (no entry, the dof lanes read the task block itself); a
+    // composite of up to four tasks is summed from the task blocks directly (no dependency on its children); only larger ones
+    // build on child composites.  G1: 3 dependent passes instead of 5.
+    std::vector<int> alias_task(ncomp[k], -1);
     for (int c = 0; c < ncomp[k]; ++c) {
+      const unsigned mk = compmask[k * 2 * GMR_MAX_TASKS + c];
+      if (__builtin_popcount(mk) == 1) alias_task[c] = __builtin_ctz(mk);
+    }
+    for (int i = 0; i < n_act; ++i) {
+      const int c = acomp[k * 64 + i];
+      acomp[k * 64 + i] = alias_task[c] >= 0 ? alias_task[c] : ntmax + c;  // block index from Bt on (Bc = Bt + kBT ntmax)
+    }
+    for (int c = 0; c < ncomp[k]; ++c) {
+      if (alias_task[c] >= 0) continue;
+      const unsigned mk = compmask[k * 2 * GMR_MAX_TASKS + c];
       std::vector<int> srcs;
-      for (unsigned own = comp_own[k * 32 + c]; own; own &= own - 1) srcs.push_back(__builtin_ctz(own));
-      for (unsigned kids = comp_kids[k * 32 + c]; kids; kids &= kids - 1) srcs.push_back(64 + __builtin_ctz(kids));
+      if (__builtin_popcount(mk) <= 4) {
+        for (unsigned t = mk; t; t &= t - 1) srcs.push_back(__builtin_ctz(t));
+      } else {
+        for (unsigned own = comp_own[k * 32 + c]; own; own &= own - 1) srcs.push_back(__builtin_ctz(own));
+        for (unsigned kids = comp_kids[k * 32 + c]; kids; kids &= kids - 1) {
+          const int d = __builtin_ctz(kids);
+          srcs.push_back(alias_task[d] >= 0 ? alias_task[d] : 64 + d);
+        }
+      }
       // child composites first: the entries that wait for them should be few
       std::stable_sort(srcs.begin(), srcs.end(), [](int a, int b) { return (a >= 64) > (b >= 64); });
       size_t i = 0;
@@ -528,6 +549,7 @@ int build_device_model(gmr_model *m) {
     }
     ncpass[k] = pass;
   }
+  if (getenv("GMR_DEBUG_PLAN")) fprintf(stderr, "gmr: composite plan: %d / %d composites, %d / %d passes\n", ncomp[0], ncomp[1], ncpass[0], ncpass[1]);
   m->lay.total_doubles += 8 * (ncpass[0] + ncpass[1]);
   m->lds_bytes = m->lay.total_doubles * (int)sizeof(double);
   if (m->lds_bytes > 65535) { set_err(m, "model needs %d bytes of LDS per wavefront (plan offsets are 16 bit)", m->lds_bytes); return GMR_EUNSUPPORTED; }

@@ -988,7 +988,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
   double *q = lds + lay.q, *xpos = lds + lay.xpos, *xquat = lds + lay.xquat, *tp = lds + lay.tp, *tq = lds + lay.tq;
-  double *Bt = lds + lay.B, *Bc = lds + lay.Bc, *S = lds + lay.S, *F = lds + lay.F, *Hm = lds + lay.H;
+  double *Bt = lds + lay.B, *S = lds + lay.S, *F = lds + lay.F, *Hm = lds + lay.H;
   double *bodyc = lds + (GMR_IK_STAGE_TREE ? lay.bodyc : 0);
   if constexpr (GMR_IK_STAGE_TREE != 0) stage_tree(m, lane, bodyc);
   // Once per wavefront: the zero block (absent sources of the composite plan) and the two phase plans, from the L2-resident
@@ -1225,7 +1225,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
           double B[kBTLanes * 2];  // the composite block, seven b128 reads per half
 #pragma unroll
           for (int c = 0; c < kBTLanes; c++) {
-            const double2 v = lds2(Bc + kBT * a_comp + 2 * c);
+            const double2 v = lds2(Bt + kBT * a_comp + 2 * c);  // a_comp: block index from Bt on (a one-task composite IS the task block)
             B[2 * c] = v.x; B[2 * c + 1] = v.y;
           }
           double Fi[6];
