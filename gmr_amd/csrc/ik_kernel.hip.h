@@ -80,6 +80,7 @@ constexpr int kBT = 30, kBTLanes = 14;
 __host__ __device__ constexpr int bt_ll(int i, int j) { return i == j ? i : ((j - i + 3) % 3 == 1 ? 3 + i : 3 + j); }
 __host__ __device__ constexpr int bt_la(int i, int j) { return 3 * (2 + (j - i + 3) % 3) + i; }
 __host__ __device__ constexpr int bt_aa(int i, int j) { return i == j ? 15 + i : ((j - i + 3) % 3 == 1 ? 18 + i : 18 + j); }
+constexpr int kCompRegs = 3;     // passes of the composite plan whose addresses stay in registers for a whole stage
 constexpr int kMaxCompPass = 32;  // passes of the composite plan (two composites per pass, children before parents)
 constexpr double kLieEps = 1e-10;  // mink.lie.utils.get_epsilon(float64)
 
@@ -1177,6 +1178,19 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
       const int t_body = m.tbody[trow], t_slot = m.tslot[trow];
       const double t_wp = m.twp[trow], t_wr = m.twr[trow];
       const int a_comp = m.acomp[tab * 64 + arow];
+      // composite plan of this table: entry of quarter-wave lane >> 4 per pass = four source block offsets + destination
+      // (LDS bytes); this lane moves the 16 bytes at el16 of each block.  The first kCompRegs passes are resolved to addresses here.
+      const int np = m.ncpass[tab];
+      const unsigned el16 = 16u * (lane & 15);
+      const uint4 *cplan_tab = reinterpret_cast<const uint4 *>(lds + lay.cplan) + (tab ? 4 * m.ncpass[0] : 0) + (lane >> 4);
+      unsigned cadr[kCompRegs][5];
+#pragma unroll
+      for (int p = 0; p < kCompRegs; ++p) {
+        const uint4 e = p < np ? cplan_tab[4 * p] : uint4{0, 0, 0, 0};
+        cadr[p][0] = (e.x & 0xffffu) + el16; cadr[p][1] = (e.x >> 16) + el16;
+        cadr[p][2] = (e.y & 0xffffu) + el16; cadr[p][3] = (e.y >> 16) + el16;
+        cadr[p][4] = e.z + el16;
+      }
 
       double e[6] = {0, 0, 0, 0, 0, 0}, jl_kap = 0.0, jl_bet = 0.0;  // kap, bet of Jl^-1: from the residual to the task block
       // q has not moved since the FK that closed the previous solve (previous stage or previous frame): the poses in LDS
@@ -1244,21 +1258,23 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
                       // composite.  A quarter's plan entry is four source block offsets (absent ones point at the zero block) and a
                       // destination; no masks, no selects.  Same wave, so LDS program order makes a pass see the previous one's
                       // writes without a barrier.
-          const int np = m.ncpass[tab];
-          if ((lane & 15) < kBTLanes) {
+          if (__builtin_amdgcn_inverse_ballot_w64(kmask<0x3fff3fffu>())) {  // (lane & 15) < kBTLanes
             char *lb = reinterpret_cast<char *>(lds);
-            const unsigned el16 = 16u * (lane & 15);
-            const uint4 *plan = reinterpret_cast<const uint4 *>(lds + lay.cplan) + (tab ? 4 * m.ncpass[0] : 0) + (lane >> 4);
-            uint4 nxt = plan[0];
-            for (int p = 0; p < np; ++p) {
-              const uint4 cur = nxt;
-              if (p + 1 < np) nxt = plan[4 * (p + 1)];
-              const double2 v0 = *reinterpret_cast<const double2 *>(lb + ((cur.x & 0xffffu) + el16)), v1 = *reinterpret_cast<const double2 *>(lb + ((cur.x >> 16) + el16));
-              const double2 v2 = *reinterpret_cast<const double2 *>(lb + ((cur.y & 0xffffu) + el16)), v3 = *reinterpret_cast<const double2 *>(lb + ((cur.y >> 16) + el16));
+            auto pass = [&](unsigned s0, unsigned s1, unsigned s2, unsigned s3, unsigned dst) {
+              const double2 v0 = *reinterpret_cast<const double2 *>(lb + s0), v1 = *reinterpret_cast<const double2 *>(lb + s1);
+              const double2 v2 = *reinterpret_cast<const double2 *>(lb + s2), v3 = *reinterpret_cast<const double2 *>(lb + s3);
               double2 sum;
               sum.x = (v0.x + v1.x) + (v2.x + v3.x);
               sum.y = (v0.y + v1.y) + (v2.y + v3.y);
-              *reinterpret_cast<double2 *>(lb + ((cur.z | cur.w) + el16)) = sum;  // (w is 0: keeps the plan read a b128, not a half-rate b96)
+              *reinterpret_cast<double2 *>(lb + dst) = sum;
+            };
+            // the first kCompRegs passes run from addresses resolved at the stage's entry (no plan read, no unpacking)
+#pragma unroll
+            for (int p = 0; p < kCompRegs; ++p)
+              if (p < np) pass(cadr[p][0], cadr[p][1], cadr[p][2], cadr[p][3], cadr[p][4]);
+            for (int p = kCompRegs; p < np; ++p) {
+              const uint4 cur = cplan_tab[4 * p];
+              pass((cur.x & 0xffffu) + el16, (cur.x >> 16) + el16, (cur.y & 0xffffu) + el16, (cur.y >> 16) + el16, (cur.z | cur.w) + el16);
             }
           }
         }
