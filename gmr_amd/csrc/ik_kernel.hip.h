@@ -80,6 +80,7 @@ constexpr int kBT = 30, kBTLanes = 14;
 __host__ __device__ constexpr int bt_ll(int i, int j) { return i == j ? i : ((j - i + 3) % 3 == 1 ? 3 + i : 3 + j); }
 __host__ __device__ constexpr int bt_la(int i, int j) { return 3 * (2 + (j - i + 3) % 3) + i; }
 __host__ __device__ constexpr int bt_aa(int i, int j) { return i == j ? 15 + i : ((j - i + 3) % 3 == 1 ? 18 + i : 18 + j); }
+constexpr int kHPlanRegs = 6;    // rounds of the H pair plan held in registers (even)
 constexpr int kCompRegs = 3;     // passes of the composite plan whose addresses stay in registers for a whole stage
 constexpr int kMaxCompPass = 32;  // passes of the composite plan (two composites per pass, children before parents)
 constexpr double kLieEps = 1e-10;  // mink.lie.utils.get_epsilon(float64)
@@ -1038,6 +1039,9 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
     for (int i = lane; i < n1; i += 64) cp[n0 + i] = m.comp_plan[4 * kMaxCompPass + i];
   }
   const gmr_work_item w = L.items[blockIdx.x];
+  uint2 hreg[kHPlanRegs];  // this lane's entries of the first rounds of the H pair plan
+#pragma unroll
+  for (int r = 0; r < kHPlanRegs; ++r) hreg[r] = 64 * r < m.npairp ? m.hplan[64 * r + lane] : uint2{0, 0};
   FkJump fkj;  // (lane = body; bodies beyond the tree and finished chains fetch from themselves and do not fold)
   {
     const u64 an = lane < m.nbody ? m.fkanc[lane] : ~0ull;
@@ -1307,16 +1311,12 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         // every structurally non-zero off-diagonal pair (i below j): H[i][j] = H[j][i] = S_j . F_i, spread over all lanes by a
         // host-made plan of LDS byte offsets (padding entries land in the dummy slots)
         auto h_pairs = [&]() {
-          // Two rounds of 64 pairs per iteration (the plan is padded to a multiple of 128): the twelve gathers of an iteration are
-          // in flight together and its two dot-product chains interleave, and the next iteration's plan entries are read while
-          // this one computes -- per-round branches used to serialise read -> wait -> chain -> write five times over.
+          // Two rounds of 64 pairs at a time (the plan is padded to a multiple of 128): their twelve gathers are in flight together
+          // and the two dot-product chains interleave -- per-round branches used to serialise read -> wait -> chain -> write five
+          // times over.  Plans of up to kHPlanRegs rounds (G1: 5) sit in registers for the whole work item; longer ones are read
+          // from their LDS copy, one iteration ahead.
           char *lb = reinterpret_cast<char *>(lds);
-          const uint2 *hp = reinterpret_cast<const uint2 *>(lds + lay.hplan) + lane;
-          const int n2 = npairp >> 7;
-          uint2 pa = hp[0], pb = hp[64];
-          for (int it = 0; it < n2; ++it) {
-            const uint2 ca = pa, cb = pb;
-            if (it + 1 < n2) { pa = hp[128 * (it + 1)]; pb = hp[128 * (it + 1) + 64]; }
+          auto two_rounds = [&](const uint2 ca, const uint2 cb) {
             const double2 *Sa = reinterpret_cast<const double2 *>(lb + (ca.x & 0xffffu)), *Fa = reinterpret_cast<const double2 *>(lb + (ca.x >> 16));
             const double2 *Sb = reinterpret_cast<const double2 *>(lb + (cb.x & 0xffffu)), *Fb = reinterpret_cast<const double2 *>(lb + (cb.x >> 16));
             const double2 a0 = Sa[0], a1 = Sa[1], a2 = Sa[2], f0 = Fa[0], f1 = Fa[1], f2 = Fa[2];
@@ -1327,6 +1327,20 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
             *reinterpret_cast<double *>(lb + (ca.y >> 16)) = da;
             *reinterpret_cast<double *>(lb + (cb.y & 0xffffu)) = db;
             *reinterpret_cast<double *>(lb + (cb.y >> 16)) = db;
+          };
+          if (npairp <= 64 * kHPlanRegs) {  // wave-uniform
+#pragma unroll
+            for (int it = 0; it < kHPlanRegs / 2; ++it)
+              if (128 * it < npairp) two_rounds(hreg[2 * it], hreg[2 * it + 1]);
+          } else {
+            const uint2 *hp = reinterpret_cast<const uint2 *>(lds + lay.hplan) + lane;
+            const int n2 = npairp >> 7;
+            uint2 pa = hp[0], pb = hp[64];
+            for (int it = 0; it < n2; ++it) {
+              const uint2 ca = pa, cb = pb;
+              if (it + 1 < n2) { pa = hp[128 * (it + 1)]; pb = hp[128 * (it + 1) + 64]; }
+              two_rounds(ca, cb);
+            }
           }
         };
         double dq;
