@@ -80,8 +80,8 @@ constexpr int kBT = 30, kBTLanes = 14;
 __host__ __device__ constexpr int bt_ll(int i, int j) { return i == j ? i : ((j - i + 3) % 3 == 1 ? 3 + i : 3 + j); }
 __host__ __device__ constexpr int bt_la(int i, int j) { return 3 * (2 + (j - i + 3) % 3) + i; }
 __host__ __device__ constexpr int bt_aa(int i, int j) { return i == j ? 15 + i : ((j - i + 3) % 3 == 1 ? 18 + i : 18 + j); }
-constexpr int kHPlanRegs = 6;    // rounds of the H pair plan held in registers (even)
-constexpr int kCompRegs = 3;     // passes of the composite plan whose addresses stay in registers for a whole stage
+constexpr int kHPlanRegsSQ = 6;  // rounds of the H pair plan held in registers (even); structured back end only -- the generic one has no registers to spare
+constexpr int kCompRegsSQ = 3;   // passes of the composite plan whose addresses stay in registers for a whole stage (ditto)
 constexpr int kMaxCompPass = 32;  // passes of the composite plan (two composites per pass, children before parents)
 constexpr double kLieEps = 1e-10;  // mink.lie.utils.get_epsilon(float64)
 
@@ -1039,7 +1039,8 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
     for (int i = lane; i < n1; i += 64) cp[n0 + i] = m.comp_plan[4 * kMaxCompPass + i];
   }
   const gmr_work_item w = L.items[blockIdx.x];
-  uint2 hreg[kHPlanRegs];  // this lane's entries of the first rounds of the H pair plan
+  constexpr int kHPlanRegs = SQ ? kHPlanRegsSQ : 0, kCompRegs = SQ ? kCompRegsSQ : 0;
+  uint2 hreg[kHPlanRegs > 0 ? kHPlanRegs : 1];  // this lane's entries of the first rounds of the H pair plan
 #pragma unroll
   for (int r = 0; r < kHPlanRegs; ++r) hreg[r] = 64 * r < m.npairp ? m.hplan[64 * r + lane] : uint2{0, 0};
   FkJump fkj;  // (lane = body; bodies beyond the tree and finished chains fetch from themselves and do not fold)
@@ -1187,7 +1188,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
       const int np = m.ncpass[tab];
       const unsigned el16 = 16u * (lane & 15);
       const uint4 *cplan_tab = reinterpret_cast<const uint4 *>(lds + lay.cplan) + (tab ? 4 * m.ncpass[0] : 0) + (lane >> 4);
-      unsigned cadr[kCompRegs][5];
+      unsigned cadr[kCompRegs > 0 ? kCompRegs : 1][5];
 #pragma unroll
       for (int p = 0; p < kCompRegs; ++p) {
         const uint4 e = p < np ? cplan_tab[4 * p] : uint4{0, 0, 0, 0};
@@ -1328,7 +1329,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
             *reinterpret_cast<double *>(lb + (cb.y & 0xffffu)) = db;
             *reinterpret_cast<double *>(lb + (cb.y >> 16)) = db;
           };
-          if (npairp <= 64 * kHPlanRegs) {  // wave-uniform
+          if (kHPlanRegs > 0 && npairp <= 64 * kHPlanRegs) {  // wave-uniform
 #pragma unroll
             for (int it = 0; it < kHPlanRegs / 2; ++it)
               if (128 * it < npairp) two_rounds(hreg[2 * it], hreg[2 * it + 1]);
