@@ -282,19 +282,23 @@ __device__ __forceinline__ void sincos_small(double x, double *sn, double *cs) {
   *sn = (n & 2) ? -s1 : s1;
   *cs = ((n + 1) & 2) ? -c1 : c1;
 }
-// atan2(y, x) for y = sin(phi) >= 0, x = cos(phi) >= 0 of ONE angle (x^2 + y^2 = 1: the scalar and vector norms of a unit
-// quaternion), phi in [0, pi/2].  Two half-angle steps need no range selection at all: cos(phi/2) = sqrt((1 + x) / 2),
-// tan(phi/4) = sin(phi/2) / (1 + cos(phi/2)) = y / (2 c (1 + c)) <= tan(pi/8) = 0.4142, inside the interval where fdlibm's
-// atan kernel is used without argument reduction; phi = 4 atan(tan(phi/4)).
-__device__ __forceinline__ double atan2_unit(double y, double x) {
+// 2 atan2(y, x) / y for y = sin(phi) >= 0, x = cos(phi) >= 0 of ONE angle (x^2 + y^2 = 1: the vector and scalar norms of a unit
+// quaternion), phi in [0, pi/2] -- the factor that turns the quaternion's vector part into the rotation vector (SO3 log).
+// Two half-angle steps need no range selection: cos(phi/2) = sqrt((1 + x) / 2), tan(phi/4) = sin(phi/2) / (1 + cos(phi/2)) =
+// y / (2 c (1 + c)) <= tan(pi/8) = 0.4142, inside the interval where fdlibm's atan kernel needs no argument reduction, so
+// atan2(y, x) = 4 t (1 - s(t^2)) with t = y r / 2, r = 1 / (c (1 + c)), and the quotient by y is 4 r (1 - s): no division by y,
+// finite and exact to rounding down to y = 0 (mink's small-angle series 2/w - 2 n^2 / (3 w^3) agrees with it to O(n^4), its
+// |w| ~ 0 case pi / n is the same expression at x = 0).
+__device__ __forceinline__ double so3_log_factor(double y, double x) {
   const double c = fast_sqrt(fma(0.5, x, 0.5));
-  const double t = y * fast_rcp(2.0 * c * (1.0 + c));
+  const double r = fast_rcp(c * (1.0 + c));
+  const double t = 0.5 * y * r;
   const double z = t * t, w = z * z;
   const double s1 = z * fma(w, fma(w, fma(w, fma(w, fma(w, kc(1.62858201153657823623e-02), kc(4.97687799461593236017e-02)), kc(6.66107313738753120669e-02)),
                                           kc(9.09088713343650656196e-02)), kc(1.42857142725034663711e-01)), kc(3.33333333333329318027e-01));
   const double s2 = w * fma(w, fma(w, fma(w, fma(w, kc(-3.65315727442169155270e-02), kc(-5.83357013379057348645e-02)), kc(-7.69187620504482999495e-02)),
                                    kc(-1.11111104054623557880e-01)), kc(-1.99999999998764832476e-01));
-  return 4.0 * (t - t * (s1 + s2));
+  return 4.0 * r * (1.0 - (s1 + s2));
 }
 
 // ------------------------------------------------------------------ quaternion / matrix helpers (wxyz)
@@ -497,19 +501,16 @@ __device__ __forceinline__ double task_residual(int body, int slot, const double
   // SO3 log, short side (mink.lie.so3.SO3.log).  n = sin and |w| = cos of half the rotation angle; the angle itself is
   // th = |f| n, which saves the square root of |om|^2.
   const double w = qr[0], n2 = qr[1] * qr[1] + qr[2] * qr[2] + qr[3] * qr[3];
-  const double n = fast_sqrt(n2), aw = fabs(w), in = fast_rcp(n);  // (in is only used where n2 >= kLieEps / 4)
-  double f, c2;
-  if (n2 < kLieEps) {
-    const double iw = fast_rcp(w);
-    f = 2.0 * iw - 2.0 / 3.0 * n2 * iw * iw * iw;
-  } else if (aw < kLieEps) f = (w > 0 ? 1.0 : -1.0) * M_PI * in;
-  else f = (w < 0 ? -2.0 : 2.0) * atan2_unit(n, aw) * in;
+  const double n = fast_sqrt(n2), aw = fabs(w);
+  // one expression for mink's three cases (n^2 < eps: series; |w| < eps: pi / n; else 2 atan2(n, |w|) / n); the sign is mink's
+  const double f = (aw < kLieEps ? (w > 0 ? 1.0 : -1.0) : (w < 0 ? -1.0 : 1.0)) * so3_log_factor(n, aw);
+  double c2;
   const double om[3] = {f * qr[1], f * qr[2], f * qr[3]};
   const double th = fabs(f) * n, th2 = th * th;
   kap = 0.0; bet = 0.0;  // the two scalars of Jl^-1 the task block needs (below mink's threshold it uses the identity)
   if (th2 < kLieEps) c2 = 1.0 / 12.0;
   else {
-    const double ith = fast_rcp(th), ith2 = ith * ith, cot = aw * in;
+    const double ith = fast_rcp(th), ith2 = ith * ith, in = fast_rcp(n), cot = aw * in;
     c2 = (1.0 - 0.5 * th * cot) * ith2;
     const double delta = 0.25 * th * in * in - 0.5 * cot;
     kap = c2;
