@@ -839,6 +839,22 @@ __device__ __forceinline__ int box_qp(int lane, int n_act, const double *Hm, dou
 // two gfx950 permlane swaps -- no LDS and no barrier inside the factorisation.  LDL' without square roots; the pivot lane
 // keeps its raw row (what the back-substitution consumes), rows below it clear their column entry so that the
 // back-substitution needs no triangle mask.  16 registers per row instead of NVP.
+// acc -= bcast_K(src) * u in ONE instruction: gfx950's v_fmac_f64 takes a DPP row_newbcast on its first operand (the only
+// float64 ALU op that does; checked on the chip, tools/dpp_fmac_probe.hip).  The source lane must be enabled in EXEC (a disabled
+// lane reads as 0).  The compiler does not see a DPP instruction inside inline asm, so the two hazards are covered by hand:
+// NOP2 = the broadcast operand was written by the VALU instruction right before (2 wait states).
+template <int K, bool NOP2 = false>
+__device__ __forceinline__ void fmac_bcast_neg(double &acc, double src, double u) {
+  if constexpr (NOP2) asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(u), "n"(K));
+  else asm("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(u), "n"(K));
+}
+// group_bcast whose source may have been written by one of the asm statements above a single instruction earlier
+template <int K>
+__device__ __forceinline__ double group_bcast_after_asm(double v) {
+  double r;
+  asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "n"(K));
+  return r;
+}
 template <int K>
 __device__ __forceinline__ double group_bcast(double v) {  // value of lane (lane & 48) + K: one v_mov_b64_dpp row_newbcast, no LDS
   return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + K, 0xf, 0xf, true);  // every lane has a source: no 'old' value to keep
@@ -965,7 +981,7 @@ __device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool 
         }
       }
       const double ck = R[k];  // this row's entry in the pivot column
-      const double invd = fast_rcp(group_bcast<k>(ck));
+      const double invd = fast_rcp(group_bcast_after_asm<k>(ck));
       const double bk = group_bcast<k>(bb);
       myinvd = invd;
       const double u = ck * invd;
@@ -977,7 +993,7 @@ __device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool 
         if (__builtin_amdgcn_inverse_ballot_w64(kmask<below16 | (below16 << 16)>())) {
           static_for<k + 1, 16>([&](auto J) {
             constexpr int jj = J;
-            R[jj] -= u * group_bcast<jj>(ck);
+            fmac_bcast_neg<jj>(R[jj], ck, u);  // R[jj] -= u * (column-k entry of row jj)
           });
           bb -= u * bk;
           self(self, std::integral_constant<int, k + 1>{});
@@ -988,7 +1004,7 @@ __device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool 
     // ---- back-substitution, k = 15 .. 0: x_k = (y_k - sum_{b>k} R_k[b] x_b) / d_k ----
     static_for_down<0, 16>([&](auto K) {  // R[k] is 0 on and left of the diagonal (cleared by the elimination)
       constexpr int k = K;
-      bb -= R[k] * group_bcast<k>(bb * myinvd);
+      fmac_bcast_neg<k, true>(bb, bb * myinvd, R[k]);  // bb -= R[k] * x_k
     });
     const double z = bb * myinvd;
     // ratio test along x -> z over the free variables (owner lanes only).  Usually nothing blocks: decide that with compares
