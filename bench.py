@@ -211,7 +211,7 @@ def main():
                     ts.append(time.perf_counter() - t1)
                 return float(np.median(ts)), r
             t_seq, (q_seq, _, _) = timed(lambda: eng.ik_solve(one_p, one_q, sc, make_items(one_offs)), reps=3)
-            t_chk, (q_chk, _, info) = timed(lambda: eng.ik_solve_chunked(one_p, one_q, sc, one_offs, chunk=8, burn_in=24))
+            t_chk, (q_chk, _, info) = timed(lambda: eng.ik_solve_chunked(one_p, one_q, sc, one_offs, chunk=16, burn_in=24))
             # live single-sequence mode (gmr_session_*): host frame in -> host qpos out, one launch per frame
             ses = eng.session(sc, int(one_p.shape[1]), dtype=np.float32)
             hp, hq = one_p[:256].cpu().numpy(), one_q[:256].cpu().numpy()
@@ -235,7 +235,7 @@ def main():
             result["host_fed"] = {"frames": nh, "frames_per_s": nh / t_host, "includes": "H2D of the key-points (392 B/frame) + kernel + D2H of qpos (288 B/frame), pageable host memory, no overlap"}
             result["single_clip"] = {
                 "frames": T, "sequential_frames_per_s": T / t_seq, "verified_chunked_frames_per_s": T / t_chk,
-                "chunk": 8, "burn_in": 24, "passes": info["passes"], "resolved_frames": info["resolved_frames"],
+                "chunk": 16, "burn_in": 24, "passes": info["passes"], "resolved_frames": info["resolved_frames"],
                 "max_abs_diff_vs_sequential": float((q_chk - q_seq).abs().max().item()), "includes": "host scheduling + verification passes",
             }
         if world == 1 and not args.no_cpu and not args.hot_only:
