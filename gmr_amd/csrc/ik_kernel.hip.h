@@ -905,6 +905,16 @@ __device__ __forceinline__ void group_sum4x4(double &x, double &y, double &p, do
   p = t2; q = t2;
   swap16(p, q);
 }
+// Two values (same pairing of the addends, so every group ends up with bitwise the same sums): 6 swaps, 4 copies, 2 adds.
+__device__ __forceinline__ void group_sum2x4(double &x, double &y) {
+  swap16(x, y);      // x = rows {x0 y0 x2 y2}, y = {x1 y1 x3 y3}
+  double z = x + y;  // {x01 y01 x23 y23}
+  double w = z;
+  swap32(z, w);      // z = {x01 y01 x01 y01}, w = {x23 y23 x23 y23}
+  const double t = z + w;  // {X Y X Y}
+  x = t; y = t;
+  swap16(x, y);      // x = {X X X X}, y = {Y Y Y Y}
+}
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F &&f) {  // f(std::integral_constant<int, I>) for I in [I, N)
   if constexpr (I < N) {
@@ -972,11 +982,13 @@ __device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool 
       if constexpr (k >= 6 && k <= 10) {
         if (k == launder_uniform(nl)) {  // first core pivot: every copy of the core block / rhs <- sum over the four groups.  Only core rows
                                          // (a >= nl) are enabled here, in every group alike; limb columns are already zero in them
-          {  // R[6..15] and bb
+          {  // R[k..15] and bb (columns left of the first core pivot are limb columns, zero in the core rows), four or two at a time
             double none = 0.0;
-            group_sum4x4(R[6], R[7], R[8], R[9]);
-            group_sum4x4(R[10], R[11], R[12], R[13]);
-            group_sum4x4(R[14], R[15], bb, none);
+            if constexpr (k == 6) { group_sum4x4(R[6], R[7], R[8], R[9]); group_sum4x4(R[10], R[11], R[12], R[13]); group_sum4x4(R[14], R[15], bb, none); }
+            if constexpr (k == 7) { group_sum4x4(R[7], R[8], R[9], R[10]); group_sum4x4(R[11], R[12], R[13], R[14]); group_sum2x4(R[15], bb); }
+            if constexpr (k == 8) { group_sum4x4(R[8], R[9], R[10], R[11]); group_sum4x4(R[12], R[13], R[14], R[15]); group_sum2x4(bb, none); }
+            if constexpr (k == 9) { group_sum4x4(R[9], R[10], R[11], R[12]); group_sum4x4(R[13], R[14], R[15], bb); }
+            if constexpr (k == 10) { group_sum4x4(R[10], R[11], R[12], R[13]); group_sum4x4(R[14], R[15], bb, none); }
           }
         }
       }
