@@ -845,14 +845,15 @@ __device__ __forceinline__ int box_qp(int lane, int n_act, const double *Hm, dou
 // NOP2 = the broadcast operand was written by the VALU instruction right before (2 wait states).
 template <int K, bool NOP2 = false>
 __device__ __forceinline__ void fmac_bcast_neg(double &acc, double src, double u) {
-  if constexpr (NOP2) asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(u), "n"(K));
-  else asm("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(u), "n"(K));
+  // (volatile: the statement must stay inside the EXEC region it was written in -- the compiler does not know it is a VALU op)
+  if constexpr (NOP2) asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(u), "n"(K));
+  else asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(u), "n"(K));
 }
 // group_bcast whose source may have been written by one of the asm statements above a single instruction earlier
 template <int K>
 __device__ __forceinline__ double group_bcast_after_asm(double v) {
   double r;
-  asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "n"(K));
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "n"(K));
   return r;
 }
 template <int K>
