@@ -685,6 +685,12 @@ int build_device_model(gmr_model *m) {
   gmr::DevModel &dm = m->dm;
   dm = gmr::DevModel{};
   dm.nbody = nb_ik; dm.nq = nq; dm.nv = nv; dm.nslot = ns; dm.root_slot = h.root_slot; dm.n_act = n_act;
+  {  // both tables used and task t of either table ties the same robot body to the same human slot: stage 2 inherits the residual
+    bool same = h.use_table[0] && h.use_table[1] && h.ntask[0] == h.ntask[1] && h.ntask[0] > 0;
+    for (int t = 0; same && t < h.ntask[0]; ++t)
+      same = tbody_ik[t] == tbody_ik[GMR_MAX_TASKS + t] && tslot[t] == tslot[GMR_MAX_TASKS + t];
+    dm.same_tasks = same ? 1 : 0;
+  }
   for (int k = 0; k < 2; ++k) { dm.ntask[k] = h.ntask[k]; dm.use_table[k] = h.use_table[k] && h.ntask[k] > 0; dm.ncomp[k] = ncomp[k]; dm.ncpass[k] = ncpass[k]; }
   dm.npairp = (int)hplan.size() / 2; dm.fkrounds = fkrounds; dm.sq_ok = sq_ok; dm.sq_nlimb = sq_nlimb;
   bool fits = true;

@@ -90,7 +90,7 @@ constexpr double kLieEps = 1e-10;  // mink.lie.utils.get_epsilon(float64)
 // of two per table (with ~45 tables passed by value the kernel spilled hundreds of SGPRs into VGPR lanes).
 constexpr int kMaxPairsPadded = (GMR_MAX_BODIES * (GMR_MAX_BODIES - 1) / 2 + 127) / 128 * 128;
 struct DevModel {
-  int nbody, nq, nv, nslot, root_slot, n_act, pad0, pad1;
+  int nbody, nq, nv, nslot, root_slot, n_act, pad0, same_tasks;  // same_tasks: both tables used, same (body, slot) per task
   int ntask[2], use_table[2], ncomp[2], ncpass[2];  // ncpass: composite passes per table
   int npairp, fkrounds, sq_ok, sq_nlimb;              // npairp: entries of hplan (a multiple of 128)
   // per active dof [64]
@@ -1221,6 +1221,10 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
     GMR_STAMP(0);
 
     int solves = 0, qpflag = 0;
+    // residual state of the task lanes: e, the two scalars of Jl^-1, row ts of R and R' x of the task body.  It outlives a stage:
+    // when both tables map the same bodies to the same targets (they differ in weights only), stage 2 starts from exactly the
+    // residual stage 1 ended with -- same poses, same targets -- and only the weighted sum is formed anew.
+    double e[6] = {0, 0, 0, 0, 0, 0}, jl_kap = 0.0, jl_bet = 0.0, t_rs[3] = {0, 0, 0}, t_xb[3] = {0, 0, 0}, sum_r2 = 0.0;
     for (int tab = 0; tab < 2; ++tab) {
       if (!m.use_table[tab]) continue;
       const int nt = m.ntask[tab];
@@ -1246,13 +1250,11 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         cadr[p][4] = e.z + el16;
       }
 
-      double e[6] = {0, 0, 0, 0, 0, 0}, jl_kap = 0.0, jl_bet = 0.0;  // kap, bet of Jl^-1: from the residual to the task block
       // q has not moved since the FK that closed the previous solve (previous stage or previous frame): the poses in LDS
       // are still those of q, so only the very first stage of a work item evaluates FK at entry.
       if (!poses_valid) fk_phase<GMR_IK_STAGE_TREE != 0>(m, bodyc, nbody, fkrounds, lane, q, xpos, xquat);
       poses_valid = true;
       GMR_STAMP(1);
-      double t_rs[3] = {0, 0, 0}, t_xb[3] = {0, 0, 0};  // row ts of R and R' x of the task body, for task_block_quad
       // |e|^2 (convergence test) and |W e|^2 (LM damping) of all tasks after one residual evaluation
       auto residual_sums = [&](double &sum_r2, double &sum_mu) {
         double r2 = 0.0, mu = 0.0;
@@ -1263,8 +1265,15 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         if (quad) quad_sum2(ts == 3 ? r2 : (ts == 2 ? mu : 0.0), sum_r2, sum_mu);
         else { sum_r2 = wave_sum(r2); sum_mu = wave_sum(mu); }
       };
-      double sum_r2, sum_mu;
-      residual_sums(sum_r2, sum_mu);
+      double sum_mu;
+      if (tab == 1 && m.same_tasks) {  // wave-uniform: e, sum_r2 carried over from stage 1; |W e|^2 with this table's weights
+        double mu = 0.0, unused;
+        if (is_task) mu = t_wp * t_wp * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) + t_wr * t_wr * (e[3] * e[3] + e[4] * e[4] + e[5] * e[5]);
+        if (quad) quad_sum2(ts == 2 ? mu : 0.0, unused, sum_mu);
+        else sum_mu = wave_sum(mu);
+      } else {
+        residual_sums(sum_r2, sum_mu);
+      }
       double curr = fast_sqrt(sum_r2);
       GMR_STAMP(2);
       int num_iter = 0;
