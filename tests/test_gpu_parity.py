@@ -83,7 +83,7 @@ def test_ik_matches_oracle_other_registry_robots(robot, dev):
     assert _qpos_diff(q.cpu().numpy(), q_ref) < 1e-6 and np.array_equal(it.cpu().numpy(), it_ref)
 
 
-def _synthetic_robot(tmp_path, limbs, with_tasks_per_limb, jrange="-1.2 1.4"):
+def _synthetic_robot(tmp_path, limbs, with_tasks_per_limb, jrange="-1.2 1.4", table2_reversed=False):
     """A floating base with `limbs` chains of hinges (list of chain lengths) hanging off it; tasks on the base and on every
     `with_tasks_per_limb`-th link of each chain.  Returns a compiled model."""
     from gmr_amd.ik_config import IKConfig, IKTask
@@ -105,7 +105,7 @@ def _synthetic_robot(tmp_path, limbs, with_tasks_per_limb, jrange="-1.2 1.4"):
     p.write_text("".join(xml))
     robot = load_mjcf(str(p))
     t1 = [IKTask(f, h, 0.0 if i % 3 else 50.0, 10.0, [0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0]) for i, (f, h) in enumerate(tasks)]
-    t2 = [IKTask(f, h, 10.0, 5.0, [0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0]) for f, h in tasks]
+    t2 = [IKTask(f, h, 10.0, 5.0, [0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0]) for f, h in (tasks[::-1] if table2_reversed else tasks)]
     cfg = IKConfig("base", "h_base", 0.0, 1.8, True, True, {h: 1.0 for _, h in tasks}, t1, t2, source="synthetic")
     return compile_model(robot, cfg)
 
@@ -136,5 +136,17 @@ def test_joint_angles_beyond_pi(dev, tmp_path):
     sc = cm.slot_columns(names)
     q_ref, it_ref, _ = orc.ik_solve(pos, quat, sc, make_items(offs))
     assert np.abs(q_ref[:, 7:]).max() > 3.3, "the case must actually leave the short path's range"
+    q, it, _ = eng.ik_solve(torch.from_numpy(pos).to(dev), torch.from_numpy(quat).to(dev), sc, make_items(offs))
+    assert _qpos_diff(q.cpu().numpy(), q_ref) < 1e-6 and np.array_equal(it.cpu().numpy() & 0x3FFFFFFF, it_ref)
+
+
+def test_tables_with_different_task_order(dev, tmp_path):
+    """Stage 2 may inherit stage 1's residual only when both tables list the same (body, target) per task; here table 2 lists
+    them in reverse order, so the kernel has to evaluate the residual again at the entry of stage 2."""
+    cm = _synthetic_robot(tmp_path, [5, 5, 4, 4], 2, table2_reversed=True)
+    eng, orc = _engine(cm), Oracle(cm.blob)
+    pos, quat, names, offs, _ = synth.synth_clips(cm, 2, 24, seed=9, hard=True, dtype=np.float64, amp=0.2)
+    sc = cm.slot_columns(names)
+    q_ref, it_ref, _ = orc.ik_solve(pos, quat, sc, make_items(offs))
     q, it, _ = eng.ik_solve(torch.from_numpy(pos).to(dev), torch.from_numpy(quat).to(dev), sc, make_items(offs))
     assert _qpos_diff(q.cpu().numpy(), q_ref) < 1e-6 and np.array_equal(it.cpu().numpy() & 0x3FFFFFFF, it_ref)
