@@ -444,7 +444,9 @@ int build_device_model(gmr_model *m) {
   int o = 0;
   L.zero = o; o += gmr::kBT;  // a block of zeros: the absent sources of the composite plan (never aliased)
   const int npairp_host = ((int)hpair.size() + 127) / 128 * 128;
-  L.hplan = o; o += npairp_host;  // H pair plan, 8 bytes per entry (staged once per wavefront)
+  // H pair plan, 8 bytes per entry, staged once per wavefront -- unless the structured kernel keeps all of it in registers
+  const bool hplan_in_regs = sq && npairp_host <= 64 * gmr::kHPlanRegsSQ;
+  L.hplan = o; o += hplan_in_regs ? 0 : npairp_host;
   L.q = o; o += even(nq);
   L.tp = o; o += even(3 * ns);
   L.tq = o; o += 4 * ns;

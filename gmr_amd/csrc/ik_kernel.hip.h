@@ -1081,7 +1081,8 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
   if (lane < kBT) lds[lay.zero + lane] = 0.0;
   {
     uint2 *hp = reinterpret_cast<uint2 *>(lds + lay.hplan);
-    for (int i = lane; i < m.npairp; i += 64) hp[i] = m.hplan[i];
+    if (!(SQ && m.npairp <= 64 * kHPlanRegsSQ))  // (a plan that fits the registers has no LDS copy)
+      for (int i = lane; i < m.npairp; i += 64) hp[i] = m.hplan[i];
     uint4 *cp = reinterpret_cast<uint4 *>(lds + lay.cplan);
     const int n0 = 4 * m.ncpass[0], n1 = 4 * m.ncpass[1];
     for (int i = lane; i < n0; i += 64) cp[i] = m.comp_plan[i];
