@@ -75,10 +75,10 @@ def host_cores() -> int:
     return max(1, n)
 
 
-# HBM bytes per output frame of ik_kernel measured with rocprofv3 PMC passes (profiles/r01_v16_pmc_*: 2 x FETCH_SIZE
+# HBM bytes per output frame of ik_kernel measured with rocprofv3 PMC passes (profiles/r01_v17_pmc_*: 2 x FETCH_SIZE
 # (gfx950 counts half, MI355X_MICROARCH.md "HBM") + WRITE_SIZE over an 8192 x 600 = 4.9152e6-frame launch):
 # 1.93 GB read + 1.44 GB written = 685 B/frame (393 + 292) against 684 algorithmic.
-MEASURED_TRAFFIC_BYTES_PER_FRAME = (2 * 942703.3 * 1024 + 1401605.8 * 1024) / 4915200.0
+MEASURED_TRAFFIC_BYTES_PER_FRAME = (2 * 942730.6 * 1024 + 1401605.1 * 1024) / 4915200.0
 
 
 def bytes_per_frame(cm, in_itemsize=4) -> int:
@@ -191,7 +191,7 @@ def main():
                 "clips_per_gpu": S, "frames_per_clip": T, "frames_per_step": n_frames * world, "parallelism": f"clip-sharded x{world}",
             },
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
-                         "traffic": MEASURED_TRAFFIC_BYTES_PER_FRAME * n_frames, "traffic_source": "profiles/r01_v16_pmc_* scaled to this launch", "kernel": f"gmr::ik_kernel<{eng.info.nv_padded}, {'true' if eng.info.reserved[0] else 'false'}>", "kernel_ms": kern_ms, "bytes_per_frame": bpf},
+                         "traffic": MEASURED_TRAFFIC_BYTES_PER_FRAME * n_frames, "traffic_source": "profiles/r01_v17_pmc_* scaled to this launch", "kernel": f"gmr::ik_kernel<{eng.info.nv_padded}, {'true' if eng.info.reserved[0] else 'false'}>", "kernel_ms": kern_ms, "bytes_per_frame": bpf},
             "valu": {"bound": "fp64-vector", "achieved": ach_tf, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": ach_tf / FP64_VECTOR_PEAK_TF,
                      "flop_per_solve": fsolve, "mean_solves_per_frame": mean_solves,
                      "solves_per_frame_histogram": solves_hist},
