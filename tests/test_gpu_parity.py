@@ -150,3 +150,22 @@ def test_tables_with_different_task_order(dev, tmp_path):
     q_ref, it_ref, _ = orc.ik_solve(pos, quat, sc, make_items(offs))
     q, it, _ = eng.ik_solve(torch.from_numpy(pos).to(dev), torch.from_numpy(quat).to(dev), sc, make_items(offs))
     assert _qpos_diff(q.cpu().numpy(), q_ref) < 1e-6 and np.array_equal(it.cpu().numpy() & 0x3FFFFFFF, it_ref)
+
+
+def test_reference_held_frame(dev, golden_dir):
+    """GPU twin of tests/test_oracle.py::test_reference_error_logs_plateau: the one IK input frame the reference holds
+    (first_frame_debug.json, fbx_to_g1.json, 1.75 m), held still for 40 frames from qpos0 -- far targets (error1 ~ 3, shoulder
+    rotation errors of 1.8 rad), the whole 22-solve budget on frame 0, active joint limits.  HIP path == oracle."""
+    from tests.test_oracle import _dumped_frame
+    cm = compiled("fbx", "unitree_g1", 1.75)
+    eng, orc = _engine(cm), Oracle(cm.blob)
+    hp, hq = _dumped_frame(golden_dir, cm)
+    pos = np.repeat(hp[None], 40, axis=0)
+    quat = np.repeat(hq[None], 40, axis=0)
+    sc = np.arange(cm.nslot, dtype=np.int32)
+    items = make_items(np.array([0, 40]))
+    q_ref, it_ref, _ = orc.ik_solve(pos, quat, sc, items)
+    q, it, _ = eng.ik_solve(torch.from_numpy(pos).to(dev), torch.from_numpy(quat).to(dev), sc, items)
+    q, it = q.cpu().numpy(), it.cpu().numpy()
+    assert it_ref[0] == 22 and (it >> 30).max() == 0
+    assert _qpos_diff(q, q_ref) < 1e-6 and np.array_equal(it, it_ref)

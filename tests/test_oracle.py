@@ -279,3 +279,46 @@ def test_reference_error_logs_error1_equals_error2(golden_dir):
         e1, _ = orc.stage_error(0, q, tp, tq, len(cm.tasks[0]))
         e2, _ = orc.stage_error(1, q, tp, tq, len(cm.tasks[1]))
         assert e1 == e2 and e1 > 0
+
+
+def _dumped_frame(golden_dir, cm):
+    """Frame 0 of one of the fork author's fbx_to_robot.py runs (first_frame_debug.json, written by scripts/fbx_to_robot.py:
+    779-788; copied as data): 101 CC_Base joints + the 14 synonym-filled IK names."""
+    import json
+    with open(os.path.join(golden_dir, "ref_fixtures", "first_frame_debug.json")) as f:
+        d = json.load(f)
+    hp = np.array([d[s]["pos"] for s in cm.slot_names], dtype=np.float64)
+    hq = np.array([d[s]["quat_wxyz"] for s in cm.slot_names], dtype=np.float64)
+    return hp, hq
+
+
+def test_reference_error_logs_plateau(golden_dir):
+    """Weak consistency with the reference's error logs -- NOT a pin (tests/golden/make_ik_pin.py documents why no logged row
+    can be reproduced: default solver OSQP, source clip absent, free numeric flags).  On the one input frame the reference
+    holds, held still, the restated loop settles on an error1 inside the band the 2 031 logged rows span, with the same
+    signature: error1 == error2, the first frame spends the whole 22-solve budget, later frames 2-3 solves."""
+    import csv
+    logged = []
+    for name in ("errors.csv", "test_errors.csv"):
+        with open(os.path.join(golden_dir, "ref_fixtures", name)) as f:
+            logged += [float(r["error1"]) for r in csv.DictReader(f)]
+    cm = compiled("fbx", "unitree_g1", 1.75)  # both loaders fall back to 1.75 m on a CC_Base skeleton (lafan1.py:66-69)
+    orc = Oracle(cm.blob)
+    hp, hq = _dumped_frame(golden_dir, cm)
+    tp, tq = orc.prepare_targets(hp, hq)
+    q = np.array(cm.robot.qpos0, dtype=np.float64)
+    e1s, solves = [], []
+    for _ in range(40):
+        q, s, _ = orc.retarget_frame(q, hp, hq)
+        e1, _ = orc.stage_error(0, q, tp, tq, len(cm.tasks[0]))
+        e2, _ = orc.stage_error(1, q, tp, tq, len(cm.tasks[1]))
+        assert e1 == e2
+        e1s.append(e1)
+        solves.append(s)
+    assert solves[0] == 22 and max(solves[10:]) <= 3
+    assert min(logged) < e1s[-1] < max(logged), (min(logged), e1s[-1], max(logged))
+    assert abs(e1s[-1] - e1s[-2]) < 1e-3
+    with open(os.path.join(golden_dir, "ik_pin_attempt.json")) as f:
+        att = __import__("json").load(f)
+    assert abs(att["default_flags_on_dumped_frame"][0][0] - e1s[0]) < 1e-9  # the committed attempt table is this oracle's
+    assert min(c[0]["worst_rel_miss"][k] for k, c in att["closest"].items()) > 0.05  # ... and records that nothing matched
