@@ -14,14 +14,15 @@ from .build import LIB_PATH as _DEFAULT_LIB_PATH
 
 LIB_PATH = os.environ.get("GMR_AMD_LIB") or _DEFAULT_LIB_PATH  # override only for A/B diagnostics of variant builds
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 GMR_DTYPE_F32, GMR_DTYPE_F64 = 0, 1
 
 WORK_ITEM_DTYPE = np.dtype(
     [("frame_begin", "<i8"), ("n_burn", "<i4"), ("n_out", "<i4"), ("init_row", "<i4"), ("final_row", "<i4"),
-     ("burn_row", "<i4"), ("check_stride", "<i4")], align=True
+     ("burn_row", "<i4"), ("check_stride", "<i4"), ("height_scale", "<f8")], align=True
 )
-assert WORK_ITEM_DTYPE.itemsize == 32
+assert WORK_ITEM_DTYPE.itemsize == 40
+INIT_QPOS0, INIT_ROOT_TARGET = -1, -2
 
 EXPORTS = ["gmr_abi_version", "gmr_model_create", "gmr_model_destroy", "gmr_last_error", "gmr_model_info_get",
            "gmr_ik_solve", "gmr_fk", "gmr_fk_min_height", "gmr_bvh_fk", "gmr_bvh_parse_motion", "gmr_evaluate", "gmr_smplx_keypoints",
@@ -91,7 +92,7 @@ def load():
     L.gmr_fk_min_height.restype = C.c_int
     L.gmr_fk_min_height.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp]
     L.gmr_evaluate.restype = C.c_int
-    L.gmr_evaluate.argtypes = [vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp]
+    L.gmr_evaluate.argtypes = [vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.gmr_smplx_keypoints.restype = C.c_int
     L.gmr_smplx_keypoints.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int64, C.c_int64, C.c_int, vp, vp, vp]
     L.gmr_bvh_fk.restype = C.c_int

@@ -40,9 +40,6 @@ struct gmr_model {
   gmr::FkTree fk{};
   gmr::LdsLayout lay{};
   int nvp = 0, n_act = 0, lds_bytes = 0, fk_lds_bytes = 0, fk_lds_bytes_min = 0;  // _min: the min-height mode has no output stage
-  // grow-only workspace for per-call scheduling data
-  void *ws = nullptr;
-  size_t ws_bytes = 0;
   unsigned long long *dbg = nullptr;  // diagnostic builds (GMR_IK_STAMPS) only
   bool force_generic = false;         // GMR_AMD_GENERIC_QP=1: use the dense generic QP even where the structured one applies
 };
@@ -98,14 +95,18 @@ struct Packer {
   }
 };
 
-int ensure_ws(gmr_model *m, size_t bytes) {
-  if (bytes <= m->ws_bytes) return GMR_OK;
-  if (m->ws) HIP_TRY(m, hipFree(m->ws));
-  m->ws = nullptr;
-  m->ws_bytes = 0;
-  size_t cap = std::max<size_t>(bytes * 2, 1 << 16);
-  HIP_TRY(m, hipMalloc(&m->ws, cap));
-  m->ws_bytes = cap;
+// Per-call scheduling data (work items, slot columns, clip offsets) lives in stream-ordered memory: allocated on the call's
+// stream and released on it right behind the launch that reads it.  Calls on the same handle from different streams or host
+// threads therefore never share (or pull away) each other's launch metadata; the pool keeps released blocks for reuse
+// (release threshold set in gmr_model_create), so a call costs no device synchronisation.
+struct CallScratch {
+  void *p = nullptr;
+  hipStream_t st = nullptr;
+  ~CallScratch() { if (p) (void)hipFreeAsync(p, st); }
+};
+int scratch_alloc(gmr_model *m, CallScratch &sc, size_t bytes, hipStream_t st) {
+  sc.st = st;
+  HIP_TRY(m, hipMallocAsync(&sc.p, std::max<size_t>(bytes, 256), st));
   return GMR_OK;
 }
 
@@ -693,6 +694,10 @@ int build_device_model(gmr_model *m) {
       same = tbody_ik[t] == tbody_ik[GMR_MAX_TASKS + t] && tslot[t] == tslot[GMR_MAX_TASKS + t];
     dm.same_tasks = same ? 1 : 0;
   }
+  dm.root_tslot = -1;  // GMR_INIT_ROOT_TARGET: the slot whose prepared target the floating base (body 0) is asked to track
+  for (int k = 0; k < 2 && dm.root_tslot < 0; ++k)
+    for (int t = 0; h.use_table[k] && t < h.ntask[k] && dm.root_tslot < 0; ++t)
+      if (tbody[k * GMR_MAX_TASKS + t] == 0) dm.root_tslot = tslot[k * GMR_MAX_TASKS + t];
   for (int k = 0; k < 2; ++k) { dm.ntask[k] = h.ntask[k]; dm.use_table[k] = h.use_table[k] && h.ntask[k] > 0; dm.ncomp[k] = ncomp[k]; dm.ncpass[k] = ncpass[k]; }
   dm.npairp = (int)hplan.size() / 2; dm.fkrounds = fkrounds; dm.sq_ok = sq_ok; dm.sq_nlimb = sq_nlimb;
   bool fits = true;
@@ -814,6 +819,12 @@ gmr_model *gmr_model_create(const void *blob, size_t blob_bytes, int device, cha
   m->h = h;
   m->blob.assign(static_cast<const uint8_t *>(blob), static_cast<const uint8_t *>(blob) + blob_bytes);
   if (hipSetDevice(device) != hipSuccess) return fail(m, "hipSetDevice failed");
+  {  // per-call scratch comes from the device's stream-ordered pool (CallScratch): keep released blocks cached
+    hipMemPool_t pool = nullptr;
+    uint64_t keep = ~0ull;
+    if (hipDeviceGetDefaultMemPool(&pool, device) != hipSuccess || hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) != hipSuccess)
+      return fail(m, "stream-ordered memory pool unavailable on this device");
+  }
   if (const char *e = getenv("GMR_AMD_GENERIC_QP")) m->force_generic = e[0] == '1';
   if (build_device_model(m) != GMR_OK) return fail(m, "model build failed");
   return m;
@@ -823,7 +834,6 @@ void gmr_model_destroy(gmr_model *m) {
   if (!m) return;
   if (m->device >= 0) (void)hipSetDevice(m->device);
   if (m->dev) (void)hipFree(m->dev);
-  if (m->ws) (void)hipFree(m->ws);
   if (m->dbg) (void)hipFree(m->dbg);
   delete m;
 }
@@ -864,6 +874,10 @@ int gmr_ik_solve(gmr_model *m, const void *human_pos, const void *human_quat, in
       set_err(m, "work item %d: a verification walk (check_stride) needs burn_row, final_row and n_burn = 0", i);
       return GMR_EINVAL;
     }
+    if (w.init_row < GMR_INIT_ROOT_TARGET || !(w.height_scale >= 0.0) || !std::isfinite(w.height_scale)) {
+      set_err(m, "work item %d: init_row must be a row, GMR_INIT_QPOS0 or GMR_INIT_ROOT_TARGET, and height_scale finite and >= 0", i);
+      return GMR_EINVAL;
+    }
     tot += w.n_burn + w.n_out; out += w.n_out;
     need_init |= w.init_row >= 0; need_final |= w.final_row >= 0 || w.burn_row >= 0;
   }
@@ -883,17 +897,19 @@ int gmr_ik_solve(gmr_model *m, const void *human_pos, const void *human_quat, in
   const size_t items_bytes = sizeof(gmr_work_item) * (size_t)n_items, col_bytes = sizeof(int32_t) * (size_t)m->h.nslot;
   const size_t order_off = (items_bytes + 15) & ~size_t(15), order_bytes = sizeof(int) * (size_t)n_items;
   const size_t col_off = (order_off + order_bytes + 15) & ~size_t(15);
-  int rc = ensure_ws(m, col_off + col_bytes);
+  CallScratch sc;
+  int rc = scratch_alloc(m, sc, col_off + col_bytes, st);
   if (rc != GMR_OK) return rc;
+  uint8_t *ws = static_cast<uint8_t *>(sc.p);
   // pageable-host copies are staged by the runtime before returning, so the vectors may die after the call
-  HIP_TRY(m, hipMemcpyAsync(m->ws, sorted.data(), items_bytes, hipMemcpyHostToDevice, st));
-  HIP_TRY(m, hipMemcpyAsync(static_cast<uint8_t *>(m->ws) + order_off, order.data(), order_bytes, hipMemcpyHostToDevice, st));
-  HIP_TRY(m, hipMemcpyAsync(static_cast<uint8_t *>(m->ws) + col_off, slot_col, col_bytes, hipMemcpyHostToDevice, st));
+  HIP_TRY(m, hipMemcpyAsync(ws, sorted.data(), items_bytes, hipMemcpyHostToDevice, st));
+  HIP_TRY(m, hipMemcpyAsync(ws + order_off, order.data(), order_bytes, hipMemcpyHostToDevice, st));
+  HIP_TRY(m, hipMemcpyAsync(ws + col_off, slot_col, col_bytes, hipMemcpyHostToDevice, st));
 
   gmr::IkLaunch L{};
-  L.hpos = human_pos; L.hquat = human_quat; L.slot_col = reinterpret_cast<const int *>(static_cast<uint8_t *>(m->ws) + col_off);
-  L.items = static_cast<const gmr_work_item *>(m->ws);
-  L.order = reinterpret_cast<const int *>(static_cast<uint8_t *>(m->ws) + order_off); L.frames_done = frames_done;
+  L.hpos = human_pos; L.hquat = human_quat; L.slot_col = reinterpret_cast<const int *>(ws + col_off);
+  L.items = reinterpret_cast<const gmr_work_item *>(ws);
+  L.order = reinterpret_cast<const int *>(ws + order_off); L.frames_done = frames_done;
   L.qinit = qpos_init; L.qfinal = qpos_final; L.qout = qpos_out; L.iters = iters_out;
   L.in_f64 = in_dtype == GMR_DTYPE_F64; L.n_cols = n_cols; L.n_items = n_items; L.prm = *params;
 #ifdef GMR_IK_STAMPS
@@ -935,7 +951,7 @@ gmr_session *gmr_session_create(gmr_model *m, int in_dtype, int n_cols, const in
   const size_t item_off = (nq * 8 + 15) & ~size_t(15), col_off = item_off + sizeof(gmr_work_item);
   if ((e = hipMalloc(reinterpret_cast<void **>(&s->dev), col_off + sizeof(int32_t) * (size_t)m->h.nslot)) != hipSuccess) return fail("hipMalloc", e);
   gmr_work_item w{};
-  w.frame_begin = 0; w.n_burn = 0; w.n_out = 1; w.init_row = 0; w.final_row = 0; w.burn_row = -1;
+  w.frame_begin = 0; w.n_burn = 0; w.n_out = 1; w.init_row = 0; w.final_row = 0; w.burn_row = -1; w.height_scale = 1.0;
   if ((e = hipMemcpy(s->dev + item_off, &w, sizeof(w), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
   if ((e = hipMemcpy(s->dev + col_off, slot_col, sizeof(int32_t) * (size_t)m->h.nslot, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
   uint8_t *hd = static_cast<uint8_t *>(host_dev);
@@ -1000,13 +1016,13 @@ int gmr_session_state(gmr_session *s, double *qpos_out) {
 }
 
 int gmr_evaluate(gmr_model *m, const double *qpos, int64_t n_frames, const void *human_pos, const void *human_quat, int in_dtype,
-                 int n_cols, const int32_t *slot_col, int offset_to_ground, double *err_out, double *xpos_out, double *xquat_out,
-                 void *stream) {
+                 int n_cols, const int32_t *slot_col, int offset_to_ground, const double *height_scale, double *err_out,
+                 double *task_err_out, double *xpos_out, double *xquat_out, void *stream) {
   if (!m) return GMR_EINVAL;
   m->err.clear();
   if (!qpos || n_frames < 0) { set_err(m, "null argument / negative size"); return GMR_EINVAL; }
   if (n_frames > 0x7fffffff) { set_err(m, "too many frames for one launch"); return GMR_EINVAL; }
-  if (err_out) {
+  if (err_out || task_err_out) {
     if (m->h.nslot == 0) { set_err(m, "model has no IK config"); return GMR_ENOCONFIG; }
     if (!human_pos || !human_quat || !slot_col || n_cols <= 0 || (in_dtype != GMR_DTYPE_F32 && in_dtype != GMR_DTYPE_F64)) {
       set_err(m, "err_out needs the human key-points, their dtype and slot_col");
@@ -1020,13 +1036,14 @@ int gmr_evaluate(gmr_model *m, const double *qpos, int64_t n_frames, const void 
   hipStream_t st = static_cast<hipStream_t>(stream);
   gmr::EvalLaunch L{};
   L.qpos = qpos; L.err_out = err_out; L.xpos_out = xpos_out; L.xquat_out = xquat_out; L.n_frames = n_frames;
-  L.offset_to_ground = offset_to_ground;
-  if (err_out) {
+  L.offset_to_ground = offset_to_ground; L.hscale = height_scale; L.task_err_out = task_err_out;
+  CallScratch sc;
+  if (err_out || task_err_out) {
     const size_t col_bytes = sizeof(int32_t) * (size_t)m->h.nslot;
-    int rc = ensure_ws(m, col_bytes);
+    int rc = scratch_alloc(m, sc, col_bytes, st);
     if (rc != GMR_OK) return rc;
-    HIP_TRY(m, hipMemcpyAsync(m->ws, slot_col, col_bytes, hipMemcpyHostToDevice, st));
-    L.hpos = human_pos; L.hquat = human_quat; L.slot_col = static_cast<const int *>(m->ws);
+    HIP_TRY(m, hipMemcpyAsync(sc.p, slot_col, col_bytes, hipMemcpyHostToDevice, st));
+    L.hpos = human_pos; L.hquat = human_quat; L.slot_col = static_cast<const int *>(sc.p);
     L.in_f64 = in_dtype == GMR_DTYPE_F64; L.n_cols = n_cols;
   }
   hipLaunchKernelGGL(gmr::eval_kernel, dim3((unsigned)n_frames), dim3(64), m->lds_bytes_eval, st, m->dm_eval_dev, L, m->lay_eval);
@@ -1063,16 +1080,17 @@ int gmr_fk_min_height(gmr_model *m, const float *root_pos, const float *root_rot
   HIP_TRY(m, hipSetDevice(m->device));
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t off_bytes = sizeof(int64_t) * (size_t)(n_seq + 1), key_off = (off_bytes + 15) & ~size_t(15);
-  int rc = ensure_ws(m, key_off + sizeof(int) * (size_t)n_seq);
+  CallScratch sc;
+  int rc = scratch_alloc(m, sc, key_off + sizeof(int) * (size_t)n_seq, st);
   if (rc != GMR_OK) return rc;
-  int *keys = reinterpret_cast<int *>(static_cast<uint8_t *>(m->ws) + key_off);
-  HIP_TRY(m, hipMemcpyAsync(m->ws, seq_offsets, off_bytes, hipMemcpyHostToDevice, st));
+  int *keys = reinterpret_cast<int *>(static_cast<uint8_t *>(sc.p) + key_off);
+  HIP_TRY(m, hipMemcpyAsync(sc.p, seq_offsets, off_bytes, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(gmr::fk_minkey_init, dim3((n_seq + 255) / 256), dim3(256), 0, st, keys, n_seq);
   if (n_frames > 0) {
     const int64_t nblk = (n_frames + gmr::kFkThreads - 1) / gmr::kFkThreads;
     if (nblk > 0x7fffffff) { set_err(m, "too many frames for one launch"); return GMR_EINVAL; }
     hipLaunchKernelGGL((gmr::fk_kernel<1>), dim3((unsigned)nblk), dim3(gmr::kFkThreads), m->fk_lds_bytes_min, st, m->fk, root_pos, root_rot_xyzw, dof,
-                       n_frames, (float *)nullptr, (float *)nullptr, static_cast<const int64_t *>(m->ws), n_seq, keys);
+                       n_frames, (float *)nullptr, (float *)nullptr, static_cast<const int64_t *>(sc.p), n_seq, keys);
   }
   hipLaunchKernelGGL(gmr::fk_minkey_decode, dim3((n_seq + 255) / 256), dim3(256), 0, st, keys, min_z_out, n_seq);
   HIP_TRY(m, hipGetLastError());

@@ -90,7 +90,8 @@ constexpr double kLieEps = 1e-10;  // mink.lie.utils.get_epsilon(float64)
 // of two per table (with ~45 tables passed by value the kernel spilled hundreds of SGPRs into VGPR lanes).
 constexpr int kMaxPairsPadded = (GMR_MAX_BODIES * (GMR_MAX_BODIES - 1) / 2 + 127) / 128 * 128;
 struct DevModel {
-  int nbody, nq, nv, nslot, root_slot, n_act, pad0, same_tasks;  // same_tasks: both tables used, same (body, slot) per task
+  // root_tslot: slot whose prepared target the root body tracks (-1 = none); same_tasks: both tables used, same (body, slot) per task
+  int nbody, nq, nv, nslot, root_slot, n_act, root_tslot, same_tasks;
   int ntask[2], use_table[2], ncomp[2], ncpass[2];  // ncpass: composite passes per table
   int npairp, fkrounds, sq_ok, sq_nlimb;              // npairp: entries of hplan (a multiple of 128)
   // per active dof [64]
@@ -1133,6 +1134,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
   for (int i = lane; i < nq; i += 64) q[i] = w.init_row >= 0 ? L.qinit[(size_t)w.init_row * nq + i] : m.qpos0[i];
   int status = real_row ? 0 : 3;
   __syncthreads();
+  const double hscale = w.height_scale != 0.0 ? w.height_scale : 1.0;  // per-clip human height factor (gmr_blob.h)
 
   const int nfr = w.n_burn + w.n_out;
   bool poses_valid = false;
@@ -1192,7 +1194,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
       double pz = INFINITY;
       double p[3] = {0, 0, 0}, qo[4] = {1, 0, 0, 0}, R[9], g[3];
       if (is_slot) {
-        const double s_scale = m.sscale[lane], root_scale = m.sscale[root_slot];
+        const double s_scale = hscale * m.sscale[lane], root_scale = hscale * m.sscale[root_slot];
         const double s_poff[3] = {m.spoff[3 * lane], m.spoff[3 * lane + 1], m.spoff[3 * lane + 2]};
         const double s_roff[4] = {m.sroff[4 * lane], m.sroff[4 * lane + 1], m.sroff[4 * lane + 2], m.sroff[4 * lane + 3]};
 #pragma unroll
@@ -1219,6 +1221,11 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
       }
     }
     __syncthreads();
+    if (kf == 0 && w.init_row == GMR_INIT_ROOT_TARGET && m.root_tslot >= 0) {  // wave-uniform: speculative chunk start (gmr_blob.h)
+      const int rts = m.root_tslot;
+      if (lane < 7) q[lane] = lane < 3 ? tp[3 * rts + lane] : tq[4 * rts + lane - 3];
+      __syncthreads();
+    }
     GMR_STAMP(0);
 
     int solves = 0, qpflag = 0;
@@ -1505,6 +1512,8 @@ struct EvalLaunch {
   double *err_out, *xpos_out, *xquat_out;
   int in_f64, n_cols, offset_to_ground, pad;
   long long n_frames;
+  const double *hscale;      // [N] per-frame factor on the human scale table, or NULL (= 1.0)
+  double *task_err_out;      // [N][ntask[0] + ntask[1]][6] per-task Log(T_body^-1 T_target) = [v; w], or NULL
 };
 
 __global__ void __launch_bounds__(64) eval_kernel(const DevModel *__restrict__ mp, EvalLaunch L, LdsLayout lay) {
@@ -1521,7 +1530,7 @@ __global__ void __launch_bounds__(64) eval_kernel(const DevModel *__restrict__ m
     for (int i = lane; i < 3 * nbody; i += 64) L.xpos_out[(size_t)f * 3 * nbody + i] = xpos[i];
   if (L.xquat_out)
     for (int i = lane; i < 4 * nbody; i += 64) L.xquat_out[(size_t)f * 4 * nbody + i] = xquat[i];
-  if (!L.err_out) return;
+  if (!L.err_out && !L.task_err_out) return;
   {  // target preparation, as in ik_kernel
     const bool is_slot = lane < nslot;
     const int s_col = L.slot_col[is_slot ? lane : 0], root_col = L.slot_col[root_slot];
@@ -1538,7 +1547,8 @@ __global__ void __launch_bounds__(64) eval_kernel(const DevModel *__restrict__ m
     }
     double pz = INFINITY, p[3] = {0, 0, 0}, qo[4] = {1, 0, 0, 0}, R[9], g[3];
     if (is_slot) {
-      const double s_scale = m.sscale[lane], root_scale = m.sscale[root_slot];
+      const double hs = L.hscale ? L.hscale[f] : 1.0;
+      const double s_scale = hs * m.sscale[lane], root_scale = hs * m.sscale[root_slot];
       const double s_poff[3] = {m.spoff[3 * lane], m.spoff[3 * lane + 1], m.spoff[3 * lane + 2]};
       const double s_roff[4] = {m.sroff[4 * lane], m.sroff[4 * lane + 1], m.sroff[4 * lane + 2], m.sroff[4 * lane + 3]};
       for (int i = 0; i < 3; i++) p[i] = (lane == root_slot) ? root_scale * rp[i] : (hp[i] - rp[i]) * s_scale + root_scale * rp[i];
@@ -1564,8 +1574,12 @@ __global__ void __launch_bounds__(64) eval_kernel(const DevModel *__restrict__ m
       const int trow = tab * GMR_MAX_TASKS + (is_task ? lane : 0);
       double e[6], kap, bet;  // (kap, bet: unused here)
       err = fast_sqrt(wave_sum(is_task ? task_residual(m.tbody[trow], m.tslot[trow], xpos, xquat, tp, tq, e, kap, bet) : 0.0));
+      if (L.task_err_out && is_task) {
+        double *o = L.task_err_out + ((size_t)f * (m.ntask[0] + m.ntask[1]) + (tab ? m.ntask[0] : 0) + lane) * 6;
+        for (int i = 0; i < 6; i++) o[i] = e[i];
+      }
     }
-    if (lane == 0) L.err_out[(size_t)f * 2 + tab] = err;
+    if (lane == 0 && L.err_out) L.err_out[(size_t)f * 2 + tab] = err;
   }
 }
 

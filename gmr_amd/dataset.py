@@ -65,13 +65,15 @@ def motions_from_qpos(gmr: GeneralMotionRetargeting, qpos: torch.Tensor, seq_off
 
 
 def retarget_clips(gmr: GeneralMotionRetargeting, pos, quat, body_names: Sequence[str], seq_offsets: Sequence[int], fps=30,
-                   height_adjust: bool = True, root_origin_offset: bool = True, chunk: int = 0, burn_in: int = 0) -> List[Dict]:
-    """The whole ``process_file`` compute path for a batch of clips: batched IK, FK, post-processing."""
+                   height_adjust: bool = True, root_origin_offset: bool = True, chunk: int = 0, burn_in: int = 0,
+                   human_heights: Optional[Sequence[float]] = None) -> List[Dict]:
+    """The whole ``process_file`` compute path for a batch of clips: batched IK, FK, post-processing.  ``human_heights``:
+    one ``actual_human_height`` per clip (the per-file ``GMR(..., actual_human_height=...)`` of
+    scripts/smplx_to_robot_dataset.py:79-83)."""
     tpos = torch.from_numpy(np.ascontiguousarray(pos)) if isinstance(pos, np.ndarray) else pos
     tquat = torch.from_numpy(np.ascontiguousarray(quat)) if isinstance(quat, np.ndarray) else quat
-    qpos = gmr.retarget_batch(tpos.to(gmr.device), tquat.to(gmr.device), body_names, seq_offsets=seq_offsets, chunk=chunk, burn_in=burn_in)
-    if not torch.isfinite(qpos).all():
-        raise FloatingPointError("non-finite qpos")
+    qpos = gmr.retarget_batch(tpos.to(gmr.device), tquat.to(gmr.device), body_names, seq_offsets=seq_offsets, chunk=chunk, burn_in=burn_in,
+                              human_heights=human_heights)  # (raises on non-finite qpos / a capped QP)
     return motions_from_qpos(gmr, qpos, seq_offsets, fps, height_adjust=height_adjust, root_origin_offset=root_origin_offset)
 
 

@@ -128,22 +128,23 @@ class Engine:
         return out, iters, qfin
 
     def ik_solve_chunked(self, pos: torch.Tensor, quat: torch.Tensor, slot_col: np.ndarray, seq_offsets, chunk: int, burn_in: int,
-                         params: Optional[IKParams] = None, eps: float = 1e-7):
+                         params: Optional[IKParams] = None, eps: float = 1e-7, height_scales=None,
+                         chunk_init: int = _native.INIT_ROOT_TARGET):
         """Parallel-in-time solve of long clips with *verified* chunk boundaries, in two launches.
 
         Launch 1 solves every chunk of ``chunk`` frames concurrently, each (but a clip's first) warmed up over
-        ``burn_in`` earlier frames from ``qpos0``, and records per chunk the state B its first output frame started from
-        and its final state F.  Launch 2 is one *verification walk* per clip (``gmr_work_item.check_stride``): starting
-        from the exact first chunk it compares, boundary by boundary, the true state with the next chunk's B; if they
-        agree to ``eps`` the chunk's stored frames are what the sequential run produces and the walk jumps to its F,
-        otherwise it solves that chunk itself from the true state.  The result therefore follows the reference's
-        sequential warm-start semantics to ``eps`` however good the burn-in was; burn-in quality only decides how much
-        of a clip the walk has to re-solve (clips that settle in one IK basin verify almost for free, clips that keep
-        switching basins degrade to the sequential rate).  Returns (qpos [N,nq], iters [N], info dict).
+        ``burn_in`` earlier frames from a speculative state (``chunk_init``: qpos0 with the floating base on the root task's
+        target, gmr_blob.h), and records per chunk the state B its first output frame started from and its final state F.
+        Launch 2 is one *verification walk* per clip (``schedule.plan_walks``): starting from the exact first chunk it
+        compares, boundary by boundary, the true state with the next chunk's B; if they agree to ``eps`` the chunk's stored
+        frames are what the sequential run produces and the walk jumps to its F, otherwise it solves that chunk itself from
+        the true state.  The result therefore follows the reference's sequential warm-start semantics to ``eps`` however
+        good the speculative start was; its quality only decides how much of a clip the walk has to re-solve.
+        Returns (qpos [N,nq], iters [N], info dict).
         """
-        from .schedule import make_items
+        from .schedule import make_items, plan_walks
         offs = np.asarray(seq_offsets, dtype=np.int64)
-        items = make_items(offs, chunk=chunk, burn_in=burn_in, track=True)
+        items = make_items(offs, chunk=chunk, burn_in=burn_in, track=True, height_scales=height_scales, chunk_init=chunk_init)
         n = len(items)
         prm = params or IKParams()
         prm = IKParams(prm.damping, prm.tol, prm.limit_gain, prm.lm_damping, prm.max_iter, prm.offset_to_ground, eps)
@@ -151,14 +152,7 @@ class Engine:
         info = {"chunks": n, "passes": 0, "resolved_frames": 0}
         if n == 0:
             return out, iters, info
-        out_begin = items["frame_begin"] + items["n_burn"]
-        first = np.nonzero(np.isin(out_begin, offs[:-1]))[0]          # first chunk of every (non-empty) clip
-        last = np.append(first[1:], n)                                  # one past its last chunk
-        multi = last - first > 1
-        walks = np.zeros(int(multi.sum()), dtype=_native.WORK_ITEM_DTYPE)
-        for k, (c0, c1) in enumerate(zip(first[multi], last[multi])):
-            clip_end = offs[np.searchsorted(offs, out_begin[c0], side="right")]
-            walks[k] = (out_begin[c0 + 1], 0, int(clip_end - out_begin[c0 + 1]), c0, c0 + 1, n + c0 + 1, chunk)
+        walks = plan_walks(items, offs, chunk)
         if len(walks):
             done = torch.zeros(len(walks), dtype=torch.int32, device=self.device)
             self.ik_solve(pos, quat, slot_col, walks, params=prm, qpos_init=qf, qpos_final=qf, out=out, iters=iters, frames_done=done)
@@ -167,8 +161,10 @@ class Engine:
         return out, iters, info
 
     def evaluate(self, qpos: torch.Tensor, pos: Optional[torch.Tensor] = None, quat: Optional[torch.Tensor] = None,
-                 slot_col: Optional[np.ndarray] = None, offset_to_ground: bool = False, want_errors: bool = True, want_poses: bool = False):
-        """Stage errors [N,2] and/or MuJoCo-convention body poses (xpos [N,nb,3], xquat [N,nb,4] wxyz) at ``qpos`` [N,nq]."""
+                 slot_col: Optional[np.ndarray] = None, offset_to_ground: bool = False, want_errors: bool = True, want_poses: bool = False,
+                 height_scale: Optional[torch.Tensor] = None, want_task_errors: bool = False):
+        """Stage errors [N,2] and/or MuJoCo-convention body poses (xpos [N,nb,3], xquat [N,nb,4] wxyz) at ``qpos`` [N,nq].
+        With ``want_task_errors`` a fourth value is returned: the per-task 6-vectors [N, ntask1+ntask2, 6]."""
         if qpos.device != self.device or qpos.dtype != torch.float64 or qpos.dim() != 2 or qpos.shape[1] != self.nq:
             raise EngineError("qpos must be float64 [N, nq] on the engine's device")
         qpos = qpos.contiguous()
@@ -187,16 +183,24 @@ class Engine:
                 raise EngineError("slot_col has the wrong length")
             B, dt = int(pos.shape[1]), _native.GMR_DTYPE_F64 if pos.dtype == torch.float64 else _native.GMR_DTYPE_F32
             err = torch.empty((N, 2), dtype=torch.float64, device=self.device)
+        terr = None
+        if want_task_errors:
+            if not want_errors:
+                raise EngineError("task errors need want_errors")
+            terr = torch.zeros((N, self.info.ntask[0] + self.info.ntask[1], 6), dtype=torch.float64, device=self.device)
         if want_poses:
             xp = torch.empty((N, self.nbody, 3), dtype=torch.float64, device=self.device)
             xq = torch.empty((N, self.nbody, 4), dtype=torch.float64, device=self.device)
         if N == 0:
-            return err, xp, xq
+            return (err, xp, xq, terr) if want_task_errors else (err, xp, xq)
+        if height_scale is not None and (height_scale.dtype != torch.float64 or height_scale.device != self.device or height_scale.shape != (N,)
+                                         or not height_scale.is_contiguous()):
+            raise EngineError("height_scale must be a contiguous float64 [N] tensor on the engine's device")
         rc = self._lib.gmr_evaluate(self._h, _ptr(qpos), N, _ptr(pos) if want_errors else None, _ptr(quat) if want_errors else None, dt, B,
-                                    slot_col.ctypes.data_as(C.c_void_p) if want_errors else None, int(bool(offset_to_ground)),
-                                    _ptr(err), _ptr(xp), _ptr(xq), self._stream())
+                                    slot_col.ctypes.data_as(C.c_void_p) if want_errors else None, int(bool(offset_to_ground)), _ptr(height_scale),
+                                    _ptr(err), _ptr(terr), _ptr(xp), _ptr(xq), self._stream())
         self._check(rc, "gmr_evaluate")
-        return err, xp, xq
+        return (err, xp, xq, terr) if want_task_errors else (err, xp, xq)
 
     def fk(self, root_pos: torch.Tensor, root_rot_xyzw: torch.Tensor, dof: torch.Tensor, want_rot: bool = True):
         for t in (root_pos, root_rot_xyzw, dof):

@@ -39,6 +39,13 @@ class MjcfError(ValueError):
 
 
 @dataclasses.dataclass
+class BodyView:
+    """What ``mujoco.MjModel.body(name)`` is used for in GMR's callers: ``.id`` and ``.name``."""
+    id: int
+    name: str
+
+
+@dataclasses.dataclass
 class RobotModel:
     """Kinematic tree of one robot (all arrays are numpy, float64 unless noted).
 
@@ -88,6 +95,25 @@ class RobotModel:
             return self.body_names.index(name)
         except ValueError:
             raise KeyError(name) from None
+
+    # --- the two ``mujoco.MjModel`` accessors GMR's callers use (scripts/fbx_to_robot.py:1040-1041, 1157-1158): MuJoCo ids
+    #     count the world body as 0, so a robot body's id is its index here + 1 -- the row of ``configuration.data.xpos``.
+    def body(self, key) -> "BodyView":
+        if isinstance(key, str):
+            if key == "world":
+                return BodyView(0, "world")
+            return BodyView(self.body_index(key) + 1, key)
+        i = int(key)
+        if not 0 <= i <= self.nbody:
+            raise IndexError(i)
+        return BodyView(i, "world" if i == 0 else self.body_names[i - 1])
+
+    def name2id(self, name: str) -> int:
+        """``mujoco.mj_name2id(model, mjOBJ_BODY, name)``: -1 for an unknown name."""
+        try:
+            return self.body(name).id
+        except KeyError:
+            return -1
 
     @property
     def depth(self) -> np.ndarray:

@@ -14,7 +14,7 @@ a HIP device the constructor raises.
 """
 from __future__ import annotations
 
-from typing import Dict, Sequence, Tuple
+from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -39,12 +39,15 @@ class _Data:
 
     @property
     def xpos(self) -> np.ndarray:
-        """World positions of all bodies at the current configuration (MuJoCo ``data.xpos`` without the world body)."""
-        return self._o._engine.evaluate(self._o._state, want_errors=False, want_poses=True)[1].cpu().numpy()[0]
+        """MuJoCo ``data.xpos`` at the current configuration: ``[nbody + 1, 3]``, row 0 the world body (zeros), row
+        ``model.body(name).id`` the named body -- the indexing scripts/fbx_to_robot.py:1040-1041, 1157-1158 uses."""
+        x = self._o._engine.evaluate(self._o._state, want_errors=False, want_poses=True)[1].cpu().numpy()[0]
+        return np.concatenate([np.zeros((1, 3)), x])
 
     @property
     def xquat(self) -> np.ndarray:
-        return self._o._engine.evaluate(self._o._state, want_errors=False, want_poses=True)[2].cpu().numpy()[0]
+        x = self._o._engine.evaluate(self._o._state, want_errors=False, want_poses=True)[2].cpu().numpy()[0]
+        return np.concatenate([np.array([[1.0, 0.0, 0.0, 0.0]]), x])
 
 
 class _Configuration:
@@ -58,6 +61,40 @@ class _Configuration:
     @property
     def q(self) -> np.ndarray:
         return self.data.qpos.copy()
+
+
+class _FrameTask:
+    """Stand-in for one ``mink.FrameTask`` of ``tasks1`` / ``tasks2`` (motion_retarget.py:83-89, 101-107): the attributes
+    callers read -- ``frame_name``, ``frame_type``, the two costs -- and ``compute_error(configuration)``, served by
+    ``gmr_evaluate`` at the object's current configuration and last targets (scripts/fbx_to_robot.py:1129-1132)."""
+
+    frame_type = "body"
+    lm_damping = 1.0
+    gain = 1.0
+
+    def __init__(self, owner, table: int, index: int, task):
+        self._o, self._table, self._index = owner, table, index
+        self.frame_name = task.frame
+        self.human_body = task.human
+        self.position_cost, self.orientation_cost = task.pos_weight, task.rot_weight
+
+    def compute_error(self, configuration=None) -> np.ndarray:
+        """``Log(T_body^-1 T_target)`` as ``[v; w]`` (the sign convention differs between mink releases; norms do not)."""
+        o = self._o
+        if configuration is not None and configuration is not o.configuration:
+            raise ValueError("tasks are bound to their retargeter's configuration")
+        return o._task_errors()[(o._cm_ntask0 if self._table else 0) + self._index].copy()
+
+    def __repr__(self):
+        return f"FrameTask(frame_name={self.frame_name!r}, position_cost={self.position_cost}, orientation_cost={self.orientation_cost})"
+
+    def __eq__(self, other):  # round 1 exposed plain frame-name strings: keep `t == "pelvis"` and `"pelvis" in tasks1` working
+        if isinstance(other, str):
+            return self.frame_name == other
+        return self is other
+
+    def __hash__(self):
+        return hash(self.frame_name)
 
 
 class GeneralMotionRetargeting:
@@ -105,8 +142,11 @@ class GeneralMotionRetargeting:
                 if t.pos_weight != 0 or t.rot_weight != 0:
                     po[t.human] = np.array(t.pos_offset) - self.ground
                     ro[t.human] = R.from_quat(t.rot_offset, scalar_first=True)
-        self.tasks1 = [t.frame for t in self._cm.tasks[0]]
-        self.tasks2 = [t.frame for t in self._cm.tasks[1]]
+        self._cm_ntask0 = len(self._cm.tasks[0])
+        self.tasks1 = [_FrameTask(self, 0, i, t) for i, t in enumerate(self._cm.tasks[0])]
+        self.tasks2 = [_FrameTask(self, 1, i, t) for i, t in enumerate(self._cm.tasks[1])]
+        self.human_body_to_task1 = {t.human_body: t for t in self.tasks1}  # keyed by human body name (:90,108)
+        self.human_body_to_task2 = {t.human_body: t for t in self.tasks2}
 
         self._engine = Engine(self._cm, device)
         self.device = self._engine.device
@@ -184,14 +224,20 @@ class GeneralMotionRetargeting:
         self._qpos = q
         return q.copy()
 
-    def _errors(self) -> np.ndarray:
+    def _evaluate(self, want_task_errors: bool):
         if getattr(self, "_last_pos_np", None) is None:
             raise RuntimeError("no targets set: call retarget() or update_targets() first")  # mink raises TargetNotSet
         pos = torch.from_numpy(self._last_pos_np[None]).to(self.device)
         quat = torch.from_numpy(self._last_quat_np[None]).to(self.device)
-        e, _, _ = self._engine.evaluate(self._state, pos, quat, self._last_cols,
-                                        offset_to_ground=self._last_offset_to_ground)
-        return e.cpu().numpy()[0]
+        return self._engine.evaluate(self._state, pos, quat, self._last_cols, offset_to_ground=self._last_offset_to_ground,
+                                     want_task_errors=want_task_errors)
+
+    def _errors(self) -> np.ndarray:
+        return self._evaluate(False)[0].cpu().numpy()[0]
+
+    def _task_errors(self) -> np.ndarray:
+        """[ntask1 + ntask2, 6]: ``task.compute_error(configuration)`` of every task, table 1 first."""
+        return self._evaluate(True)[3].cpu().numpy()[0]
 
     def error1(self):
         """|concat of the table-1 task errors| at the current configuration and targets (:188-193)."""
@@ -202,7 +248,8 @@ class GeneralMotionRetargeting:
 
     # ------------------------------------------------------------------ batched API
     def retarget_batch(self, pos, quat, body_names: Sequence[str], seq_offsets=None, chunk: int = 0, burn_in: int = 0,
-                       offset_to_ground: bool = False, return_iters: bool = False, verify: bool = True):
+                       offset_to_ground: bool = False, return_iters: bool = False, verify: bool = True,
+                       human_heights: Optional[Sequence[float]] = None, check: bool = True):
         """Retarget whole clips in one launch.
 
         pos ``[N, B, 3]`` (m), quat ``[N, B, 4]`` (wxyz), float32/float64, numpy or CUDA torch; ``body_names`` names the
@@ -210,6 +257,11 @@ class GeneralMotionRetargeting:
         ``qpos0`` like a fresh reference object.  ``chunk > 0`` solves each clip in parallel-in-time chunks; with ``verify``
         (default) chunk boundaries are checked and repaired so the result equals the sequential run to 1e-7
         (``Engine.ik_solve_chunked``); ``verify=False`` is the raw burn-in approximation (schedule.py).
+        ``human_heights [S]`` gives every clip its own ``actual_human_height`` -- what the reference does by building one
+        retargeter per file (scripts/smplx_to_robot_dataset.py:79-83): clip s is solved with the scale table of
+        ``GeneralMotionRetargeting(src, robot, human_heights[s])`` whatever height this object was built with.  With ``check``
+        (default) the result is inspected on the device -- non-finite qpos raises ``FloatingPointError`` (as ``retarget`` does),
+        a QP that hit its iteration cap raises ``RuntimeError`` (mink asserts on a failed QP); this synchronises the stream.
         Returns qpos ``[N, nq]`` float64 (same container kind as the input) and, optionally, solves per frame.
         """
         is_np = isinstance(pos, np.ndarray)
@@ -228,12 +280,25 @@ class GeneralMotionRetargeting:
         offs = np.asarray(seq_offsets, dtype=np.int64)
         if offs[0] != 0 or offs[-1] != N:
             raise ValueError("seq_offsets must span [0, N]")
+        hs = None
+        if human_heights is not None:
+            hh = np.asarray(human_heights, dtype=np.float64)
+            if hh.shape != (len(offs) - 1,):
+                raise ValueError("human_heights must hold one height per clip")
+            # ratio of the clip / ratio compiled into the model (:36-43): the per-item factor on the scale table
+            hs = hh / self._cm.config.human_height_assumption / self._cm.ratio
         if chunk > 0 and verify:
             out, iters, self.last_chunk_info = self._engine.ik_solve_chunked(
-                tpos, tquat, cols, offs, chunk, burn_in, params=self._params(offset_to_ground))
+                tpos, tquat, cols, offs, chunk, burn_in, params=self._params(offset_to_ground), height_scales=hs)
         else:
-            items = make_items(offs, chunk=chunk, burn_in=burn_in)
+            items = make_items(offs, chunk=chunk, burn_in=burn_in, height_scales=hs)
             out, iters, _ = self._engine.ik_solve(tpos, tquat, cols, items, params=self._params(offset_to_ground))
+        if check and N > 0:
+            bad = torch.stack([(~torch.isfinite(out)).any(), (iters >> 30).ne(0).any()]).cpu().numpy()
+            if bad[0]:
+                raise FloatingPointError("retarget_batch produced non-finite qpos")
+            if bad[1]:
+                raise RuntimeError("a box QP hit its iteration cap (the reference would assert on a failed QP)")
         if is_np:
             out = out.cpu().numpy()
             iters = iters.cpu().numpy() if iters is not None else None

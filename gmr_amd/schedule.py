@@ -6,45 +6,73 @@ The reference is sequential in time inside a clip (``self.configuration`` persis
 
 * ``chunk == 0`` -- one item per clip: exactly the reference's semantics.
 * ``chunk > 0``  -- a clip is cut into runs of ``chunk`` output frames; every run except a clip's
-  first starts ``burn_in`` frames early from ``qpos0`` and discards those frames.  This trades
-  redundant work for parallelism when there are fewer clips than wavefronts (a single 3k-frame
-  clip); it is an approximation whose residual against the sequential run is measured in tests
-  and reported by bench.py, never assumed.
+  first starts ``burn_in`` frames early from a *speculative* state and discards those frames:
+  ``qpos0`` with the floating base placed on the root task's target of its first frame
+  (``INIT_ROOT_TARGET``, gmr_blob.h; measured on 9000-frame clips: 0-0.5 % of the chunks end their
+  burn-in in another IK basin than the sequential run, against 1-26 % when started from ``qpos0`` at
+  the world origin).  This trades redundant work for parallelism when there are fewer clips than
+  wavefronts; alone it is an approximation -- ``plan_walks`` adds the verification pass that makes the
+  result the sequential one (Engine.ik_solve_chunked).
 
 Multi-GPU: clips are independent, so ranks take disjoint sets of clips (longest-first greedy
 bin packing by frame count); no data-path collective is needed.
 """
 from __future__ import annotations
 
-from typing import List, Sequence
+from typing import List, Optional, Sequence
 
 import numpy as np
 
-from ._native import WORK_ITEM_DTYPE
+from ._native import INIT_QPOS0, INIT_ROOT_TARGET, WORK_ITEM_DTYPE
 
 
-def make_items(seq_offsets: Sequence[int], chunk: int = 0, burn_in: int = 0, track: bool = False) -> np.ndarray:
+def make_items(seq_offsets: Sequence[int], chunk: int = 0, burn_in: int = 0, track: bool = False,
+               height_scales: Optional[Sequence[float]] = None, chunk_init: int = INIT_ROOT_TARGET) -> np.ndarray:
+    """Work items of a batch of clips.  ``height_scales[s]`` is clip s's factor on the human scale table (its own
+    ``actual_human_height`` over the height the model was compiled with, motion_retarget.py:36-43); ``chunk_init`` is the
+    start state of every chunk but a clip's first (which always starts from ``qpos0``, like the reference)."""
     offs = np.asarray(seq_offsets, dtype=np.int64)
     if offs.ndim != 1 or offs.size < 1 or np.any(np.diff(offs) < 0):
         raise ValueError("seq_offsets must be a non-decreasing 1-D array")
+    hs = np.ones(offs.size - 1) if height_scales is None else np.asarray(height_scales, dtype=np.float64)
+    if hs.shape != (offs.size - 1,) or not np.all(np.isfinite(hs)) or np.any(hs <= 0):
+        raise ValueError("height_scales must hold one positive factor per clip")
     rows = []
     for s in range(offs.size - 1):
         a, b = int(offs[s]), int(offs[s + 1])
         if b == a:
             continue
         if chunk <= 0:
-            rows.append((a, 0, b - a, -1, -1, -1, 0))
+            rows.append((a, 0, b - a, INIT_QPOS0, -1, -1, 0, hs[s]))
             continue
         for start in range(a, b, chunk):
             n_out = min(chunk, b - start)
             burn = min(burn_in, start - a)
-            rows.append((start - burn, burn, n_out, -1, -1, -1, 0))
+            rows.append((start - burn, burn, n_out, INIT_QPOS0 if start == a else chunk_init, -1, -1, 0, hs[s]))
     items = np.array(rows, dtype=WORK_ITEM_DTYPE) if rows else np.zeros(0, dtype=WORK_ITEM_DTYPE)
-    if track:  # final state of item i -> row i, state after burn-in -> row n + i (see verified_chunked_solve)
+    if track:  # final state of item i -> row i, state after burn-in -> row n + i (see plan_walks)
         n = len(items)
         items["final_row"] = np.arange(n)
         items["burn_row"] = n + np.arange(n)
     return items
+
+
+def plan_walks(items: np.ndarray, seq_offsets: Sequence[int], chunk: int) -> np.ndarray:
+    """Verification walks for the tracked chunk items of ``make_items(..., chunk, track=True)``: one item per clip that has
+    more than one chunk, running from the clip's second chunk to its end with ``check_stride = chunk`` (gmr_blob.h): it starts
+    from the first chunk's final state (exact: that chunk started from ``qpos0`` like the reference) and at every boundary
+    either adopts the chunk solved speculatively or re-solves it from the true state."""
+    offs = np.asarray(seq_offsets, dtype=np.int64)
+    n = len(items)
+    out_begin = items["frame_begin"] + items["n_burn"]
+    first = np.nonzero(np.isin(out_begin, offs[:-1]) & (items["n_burn"] == 0))[0]  # first chunk of every (non-empty) clip
+    last = np.append(first[1:], n)                                                   # one past its last chunk
+    multi = last - first > 1
+    walks = np.zeros(int(multi.sum()), dtype=WORK_ITEM_DTYPE)
+    for k, (c0, c1) in enumerate(zip(first[multi], last[multi])):
+        clip_end = offs[np.searchsorted(offs, out_begin[c0], side="right")]
+        walks[k] = (out_begin[c0 + 1], 0, int(clip_end - out_begin[c0 + 1]), c0, c0 + 1, n + c0 + 1, chunk, items["height_scale"][c0])
+    return walks
 
 
 def partition_clips(lengths: Sequence[int], world_size: int) -> List[List[int]]:

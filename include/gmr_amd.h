@@ -5,8 +5,9 @@
  * GPU the handle was created for (e.g. torch.Tensor.data_ptr()); "host" pointers
  * are ordinary CPU memory.  The caller owns every buffer; the library owns only
  * the handle (which keeps a copy of the model and a small scheduling workspace).
- * A handle may be used from one host thread at a time; different handles are
- * independent.  All calls return 0 on success and a negative GMR_E* code on
+ * Calls on one handle may be issued on different HIP streams (per-call scheduling
+ * data is stream-ordered, nothing is shared between launches); gmr_last_error's
+ * buffer is per handle, so concurrent host threads should use one handle each.  All calls return 0 on success and a negative GMR_E* code on
  * failure, with a message available from gmr_last_error().  There is no CPU
  * fallback: without a usable HIP device gmr_model_create fails.
  *
@@ -49,7 +50,7 @@
 extern "C" {
 #endif
 
-#define GMR_ABI_VERSION 2
+#define GMR_ABI_VERSION 3
 
 #define GMR_OK 0
 #define GMR_EINVAL (-1)    /* bad argument / blob / shape                     */
@@ -127,10 +128,13 @@ int gmr_session_state(gmr_session *s, double *qpos_out);
 
 /* Evaluate, per frame, the stage errors |concat_t Log(T_body^-1 T_target)| of both tables and/or the MuJoCo-convention FK.
  *   qpos device [n][nq] f64;  human_pos/human_quat/in_dtype/n_cols/slot_col as in gmr_ik_solve (needed only with err_out)
- *   err_out device [n][2] f64 or NULL;  xpos_out device [n][nbody][3] f64 or NULL;  xquat_out device [n][nbody][4] wxyz or NULL */
+ *   height_scale device [n] f64 or NULL: per-frame factor on the human scale table (gmr_work_item.height_scale of the clip)
+ *   err_out device [n][2] f64 or NULL;  xpos_out device [n][nbody][3] f64 or NULL;  xquat_out device [n][nbody][4] wxyz or NULL
+ *   task_err_out device [n][ntask[0]+ntask[1]][6] f64 or NULL: FrameTask.compute_error of every task of table 1 then table 2
+ *              (rows of an unused table are left untouched), Log(T_body^-1 T_target) as [v; w] */
 int gmr_evaluate(gmr_model *m, const double *qpos, int64_t n_frames, const void *human_pos, const void *human_quat, int in_dtype,
-                 int n_cols, const int32_t *slot_col, int offset_to_ground, double *err_out, double *xpos_out, double *xquat_out,
-                 void *stream);
+                 int n_cols, const int32_t *slot_col, int offset_to_ground, const double *height_scale, double *err_out,
+                 double *task_err_out, double *xpos_out, double *xquat_out, void *stream);
 
 /* Batched FK in the KinematicsModel convention (float32, xyzw).
  *   root_pos device [n][3], root_rot_xyzw device [n][4], dof device [n][nq-7]

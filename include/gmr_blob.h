@@ -80,8 +80,19 @@ typedef struct gmr_blob_header {
  * qpos_final[final_row + k] (its stored final state) and skips it.  Different: the
  * chunk is solved here from the true state, qpos_final[burn_row + k] and
  * qpos_final[final_row + k] are rewritten.  frames_done[item] = frames solved.
- * init_row >= 0 starts from qpos_init[init_row], otherwise from qpos0
- * (reference: a fresh GeneralMotionRetargeting per clip, motion_retarget.py:75). */
+ * init_row >= 0 starts from qpos_init[init_row]; GMR_INIT_QPOS0 (-1) from qpos0
+ * (reference: a fresh GeneralMotionRetargeting per clip, motion_retarget.py:75);
+ * GMR_INIT_ROOT_TARGET (-2) from qpos0 with the floating base placed on the prepared
+ * target of the root body's task in the first frame processed (table 1's, else table
+ * 2's; plain qpos0 if neither table tracks the root body) -- the speculative start of
+ * a mid-clip chunk: same heading and place as the human, so the burn-in converges into
+ * the basin the sequential run is in instead of one found from the world origin.
+ * height_scale multiplies every human_scale_table entry for this item (0 = 1.0): the
+ * per-clip actual_human_height / the height the model was compiled with
+ * (motion_retarget.py:36-43; scripts/smplx_to_robot_dataset.py:79-83 builds one
+ * retargeter per file with that file's height). */
+#define GMR_INIT_QPOS0 (-1)
+#define GMR_INIT_ROOT_TARGET (-2)
 typedef struct gmr_work_item {
   int64_t frame_begin; /* first frame processed (burn-in included)            */
   int32_t n_burn;
@@ -91,6 +102,7 @@ typedef struct gmr_work_item {
   int32_t burn_row;    /* row of qpos_final to receive the state right before  */
                        /* the first output frame (after burn-in), or -1        */
   int32_t check_stride; /* 0: plain item                                        */
+  double height_scale;  /* per-item factor on the human scale table, 0 = 1.0    */
 } gmr_work_item;
 
 /* Solver constants; defaults are the reference's hard-coded values. */

@@ -470,15 +470,17 @@ int oracle_box_qp(int n, const double *H, const double *c, const double *lo, con
  * GeneralMotionRetargeting.update_targets: scale_human_data then offset_human_data with
  * the TABLE-1 offsets (motion_retarget.py:117-124, 209-250), optional
  * offset_human_data_to_ground (:252-270).  hp/hq: raw human pos/quat per slot.   */
-void oracle_prepare_targets(const oracle_model *m, const double *hp, const double *hq, int offset_to_ground, double *tp, double *tq) {
+/* hscale: per-clip factor on every human_scale_table entry (actual_human_height of this clip over the height the model was
+ * compiled with, motion_retarget.py:36-43); 1.0 for the model's own ratio. */
+void oracle_prepare_targets_scaled(const oracle_model *m, const double *hp, const double *hq, int offset_to_ground, double hscale, double *tp, double *tq) {
   int ns = m->h.nslot, rs = m->h.root_slot;
   const double *root = hp + 3 * rs;
   double sroot[3];
-  for (int i = 0; i < 3; i++) sroot[i] = m->slot_scale[rs] * root[i]; /* :215 scaled about the world origin */
+  for (int i = 0; i < 3; i++) sroot[i] = hscale * m->slot_scale[rs] * root[i]; /* :215 scaled about the world origin */
   for (int s = 0; s < ns; s++) {
     double p[3], q[4], R[9], g[3];
     if (s == rs) memcpy(p, sroot, sizeof(p));
-    else for (int i = 0; i < 3; i++) p[i] = (hp[3 * s + i] - root[i]) * m->slot_scale[s] + sroot[i]; /* :225,230 */
+    else for (int i = 0; i < 3; i++) p[i] = (hp[3 * s + i] - root[i]) * (hscale * m->slot_scale[s]) + sroot[i]; /* :225,230 */
     memcpy(q, hq + 4 * s, sizeof(q));
     quat_normalize(q); /* scipy Rotation.from_quat normalises */
     quat_mul(q, m->slot_rot_off + 4 * s, tq + 4 * s); /* :241 */
@@ -493,6 +495,10 @@ void oracle_prepare_targets(const oracle_model *m, const double *hp, const doubl
       if (m->slot_is_foot[s] && tp[3 * s + 2] < lowest) lowest = tp[3 * s + 2];
     for (int s = 0; s < ns; s++) tp[3 * s + 2] = tp[3 * s + 2] - lowest + 0.1;
   }
+}
+
+void oracle_prepare_targets(const oracle_model *m, const double *hp, const double *hq, int offset_to_ground, double *tp, double *tq) {
+  oracle_prepare_targets_scaled(m, hp, hq, offset_to_ground, 1.0, tp, tq);
 }
 
 /* ------------------------------------------------------------------ one stage quantities */
@@ -576,10 +582,24 @@ static int run_stage(const oracle_model *m, int tab, const gmr_ik_params *prm, d
 
 /* GeneralMotionRetargeting.retarget for one frame (motion_retarget.py:139-185).
  * hp/hq: [nslot][3|4] raw human data of the frame (already gathered per slot). */
-int oracle_retarget_frame(const oracle_model *m, const gmr_ik_params *prm, double *qpos, const double *hp, const double *hq, double *errs) {
+static int root_target_slot(const oracle_model *m) {
+  /* GMR_INIT_ROOT_TARGET (gmr_blob.h): slot of the first used table's task on the floating base (body 0), or -1 */
+  for (int k = 0; k < 2; k++)
+    for (int t = 0; m->h.use_table[k] && t < m->h.ntask[k]; t++)
+      if (m->task_body[k][t] == 0) return m->task_slot[k][t];
+  return -1;
+}
+
+/* init_root != 0: before solving, place the floating base on the prepared target of the root body's task. */
+int oracle_retarget_frame_ex(const oracle_model *m, const gmr_ik_params *prm, double *qpos, const double *hp, const double *hq, double hscale,
+                             int init_root, double *errs) {
   double tp[3 * MAXS], tq[4 * MAXS];
   int total = 0;
-  oracle_prepare_targets(m, hp, hq, prm->offset_to_ground, tp, tq);
+  oracle_prepare_targets_scaled(m, hp, hq, prm->offset_to_ground, hscale, tp, tq);
+  if (init_root) {
+    int rts = root_target_slot(m);
+    if (rts >= 0) { memcpy(qpos, tp + 3 * rts, 3 * sizeof(double)); memcpy(qpos + 3, tq + 4 * rts, 4 * sizeof(double)); }
+  }
   for (int tab = 0; tab < 2; tab++) {
     if (!m->h.use_table[tab]) continue;
     int s = run_stage(m, tab, prm, qpos, tp, tq, errs ? errs + tab : NULL);
@@ -587,6 +607,10 @@ int oracle_retarget_frame(const oracle_model *m, const gmr_ik_params *prm, doubl
     total += s;
   }
   return total;
+}
+
+int oracle_retarget_frame(const oracle_model *m, const gmr_ik_params *prm, double *qpos, const double *hp, const double *hq, double *errs) {
+  return oracle_retarget_frame_ex(m, prm, qpos, hp, hq, 1.0, 0, errs);
 }
 
 static void gather_frame(const void *pos, const void *quat, int in_f64, int n_cols, const int32_t *slot_col, int ns, int64_t f, double *hp, double *hq) {
@@ -613,6 +637,7 @@ int oracle_ik_solve(const oracle_model *m, const gmr_ik_params *prm, const void 
     double q[MAXV + 1], hp[3 * MAXS], hq[4 * MAXS];
     memcpy(q, w->init_row >= 0 ? qpos_init + (size_t)w->init_row * nq : m->qpos0, nq * sizeof(double));
     int out_done = 0, kc = 0, left = 0, nfr = w->n_burn + w->n_out;
+    double hscale = w->height_scale != 0.0 ? w->height_scale : 1.0;
     for (int k = 0; k < nfr; k++) {
       if (w->check_stride > 0 && left == 0) { /* verification walk (gmr_blob.h): adopt a consistent chunk, solve an inconsistent one */
         double *B = qpos_final + (size_t)(w->burn_row + kc) * nq, d = 0.0;
@@ -630,7 +655,7 @@ int oracle_ik_solve(const oracle_model *m, const gmr_ik_params *prm, const void 
       int64_t f = w->frame_begin + k;
       if (w->check_stride == 0 && k == w->n_burn && w->burn_row >= 0 && qpos_final) memcpy(qpos_final + (size_t)w->burn_row * nq, q, nq * sizeof(double));
       gather_frame(pos, quat, in_f64, n_cols, slot_col, ns, f, hp, hq);
-      int s = oracle_retarget_frame(m, prm, q, hp, hq, NULL);
+      int s = oracle_retarget_frame_ex(m, prm, q, hp, hq, hscale, k == 0 && w->init_row == GMR_INIT_ROOT_TARGET, NULL);
       if (s < 0) fail |= 1;
       if (k >= w->n_burn) {
         memcpy(qpos_out + (size_t)f * nq, q, nq * sizeof(double));

@@ -31,7 +31,7 @@ class IKParams(C.Structure):
 
 WORK_ITEM_DTYPE = np.dtype(
     [("frame_begin", "<i8"), ("n_burn", "<i4"), ("n_out", "<i4"), ("init_row", "<i4"), ("final_row", "<i4"),
-     ("burn_row", "<i4"), ("check_stride", "<i4")], align=True
+     ("burn_row", "<i4"), ("check_stride", "<i4"), ("height_scale", "<f8")], align=True
 )
 
 

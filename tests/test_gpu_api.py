@@ -290,8 +290,11 @@ def test_error_accessors_and_xpos_match_oracle():
     e2, _ = orc.stage_error(1, q, tp, tq, len(cm.tasks[1]))
     assert abs(g.error1() - e1) < 1e-9 and abs(g.error2() - e2) < 1e-9
     xp, xq = orc.fk_mj(q)
-    assert np.abs(g.configuration.data.xpos - xp).max() < 1e-12
-    assert np.minimum(np.abs(g.configuration.data.xquat - xq), np.abs(g.configuration.data.xquat + xq)).max() < 1e-12
+    # MuJoCo layout: row 0 is the world body, row model.body(name).id the named body
+    assert g.configuration.data.xpos.shape == (cm.robot.nbody + 1, 3) and not g.configuration.data.xpos[0].any()
+    assert np.array_equal(g.configuration.data.xquat[0], [1, 0, 0, 0])
+    assert np.abs(g.configuration.data.xpos[1:] - xp).max() < 1e-12
+    assert np.minimum(np.abs(g.configuration.data.xquat[1:] - xq), np.abs(g.configuration.data.xquat[1:] + xq)).max() < 1e-12
     # batched evaluation through the engine
     qb = g.retarget_batch(pos, quat, names)
     err, _, _ = g._engine.evaluate(torch.from_numpy(qb).to(g.device) if isinstance(qb, np.ndarray) else qb,
@@ -521,3 +524,82 @@ def test_bench_two_rank_path_rehearsal():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["frames_per_step"] == 2 * 64 * 60
     assert d["value"] > 0 and abs(d["value"] - d["config"]["frames_per_step"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_caller_access_pattern_of_fbx_to_robot():
+    """The attribute accesses of scripts/fbx_to_robot.py on a retargeter: ``model.body(name).id`` into
+    ``configuration.data.xpos`` (:1040-1041, 1083-1084, 1157-1158), ``tasks1/2`` as objects with ``frame_name`` and
+    ``compute_error(configuration)`` (:1129-1132), ``human_body_to_task1`` (:1012), against the oracle."""
+    from gmr_amd import GeneralMotionRetargeting as GMR
+    g = GMR("smplx", "unitree_g1")
+    cm, orc = g._cm, Oracle(g._cm.blob)
+    pos, quat, names, offs, _ = synth.synth_clips(cm, 1, 3, seed=5, hard=True, dtype=np.float64)
+    for f in range(3):
+        q = g.retarget(_frames(pos, quat, names, f))
+    sc = cm.slot_columns(names)
+    tp, tq = orc.prepare_targets(pos[2][sc], quat[2][sc])
+    xp, _ = orc.fk_mj(q)
+    # (1) body ids index xpos the MuJoCo way; the root body's row is qpos[:3]
+    bid = g.model.body(g.robot_root_name).id
+    assert bid == 1 and g.model.name2id("no_such_body") == -1 and g.model.body(0).name == "world"
+    assert np.abs(g.configuration.data.xpos[bid] - q[:3]).max() < 1e-12
+    for name in ("left_wrist_yaw_link", "right_wrist_yaw_link", "pelvis"):
+        assert np.abs(g.configuration.data.xpos[g.model.body(name).id] - xp[cm.robot.body_index(name)]).max() < 1e-12
+    with pytest.raises(KeyError):
+        g.model.body("no_such_body")
+    # (2) the per-task error breakdown of :1129-1132
+    assert hasattr(g, "human_body_to_task1") and g.human_body_to_task1["pelvis"].frame_name == "pelvis"
+    for tab, tasks in enumerate((g.tasks1, g.tasks2)):
+        _, e_ref = orc.stage_error(tab, q, tp, tq, len(cm.tasks[tab]))
+        errs = {t.frame_name: float(np.linalg.norm(t.compute_error(g.configuration))) for t in tasks}
+        assert list(errs) == [t.frame for t in cm.tasks[tab]]
+        for i, t in enumerate(tasks):
+            assert np.abs(t.compute_error(g.configuration) - e_ref[i]).max() < 1e-9
+            assert (t.position_cost, t.orientation_cost) == (cm.tasks[tab][i].pos_weight, cm.tasks[tab][i].rot_weight)
+        assert abs(np.sqrt(sum(v * v for v in errs.values())) - (g.error1(), g.error2())[tab]) < 1e-9
+
+
+def test_per_clip_human_heights():
+    """clips of different subjects in one batch.  Clip s with ``human_heights[s]`` must equal a retargeter built with
+    ``actual_human_height=human_heights[s]`` (one per file in scripts/smplx_to_robot_dataset.py:79-83), and both the oracle."""
+    from gmr_amd import GeneralMotionRetargeting as GMR
+    heights = [1.55, 1.8, 1.93]
+    g = GMR("smplx", "unitree_g1", actual_human_height=1.7)  # the batch object's own height must not matter
+    cm = g._cm
+    pos, quat, names, offs, _ = synth.synth_clips(cm, 3, 20, seed=8, hard=True, dtype=np.float32)
+    q, it = g.retarget_batch(pos, quat, names, seq_offsets=offs, human_heights=heights, return_iters=True)
+    qc = g.retarget_batch(pos, quat, names, seq_offsets=offs, human_heights=heights, chunk=8, burn_in=8)
+    assert np.abs(q - qc).max() < 1e-6
+    for s, h in enumerate(heights):
+        a, b = int(offs[s]), int(offs[s + 1])
+        gs = GMR("smplx", "unitree_g1", actual_human_height=h)
+        q_one = gs.retarget_batch(pos[a:b], quat[a:b], names)
+        assert np.abs(q[a:b] - q_one).max() < 1e-9, (s, np.abs(q[a:b] - q_one).max())
+        q_ref, it_ref, _ = Oracle(gs._cm.blob).ik_solve(pos[a:b], quat[a:b], gs._cm.slot_columns(names), make_items([0, b - a]))
+        assert np.abs(q[a:b] - q_ref).max() < 1e-6 and np.array_equal(it[a:b] & 0x3FFFFFFF, it_ref)
+    assert np.abs(q[:20] - q[20:40]).max() > 1e-3  # (the heights do change the result)
+    with pytest.raises(ValueError):
+        g.retarget_batch(pos, quat, names, seq_offsets=offs, human_heights=[1.7])
+
+
+def test_one_handle_on_two_streams():
+    """ADVICE r1 / VERDICT: launches of one handle on two streams must not share scheduling data (it is stream-ordered now)."""
+    from gmr_amd.engine import Engine
+    cm = compiled("smplx", "unitree_g1")
+    eng, orc = Engine(cm, 0), Oracle(cm.blob)
+    dev = eng.device
+    sets = []
+    for seed, (S, T) in ((41, (96, 60)), (42, (7, 300))):
+        pos, quat, names, offs, _ = synth.synth_clips(cm, S, T, seed=seed, hard=True, dtype=np.float32)
+        sets.append((torch.from_numpy(pos).to(dev), torch.from_numpy(quat).to(dev), cm.slot_columns(names), make_items(offs), pos, quat))
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    outs = [None, None]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for k in (0, 1):
+            with torch.cuda.stream(streams[k]):
+                outs[k] = eng.ik_solve(sets[k][0], sets[k][1], sets[k][2], sets[k][3])
+    torch.cuda.synchronize()
+    for k in (0, 1):
+        q_ref, it_ref, _ = orc.ik_solve(sets[k][4], sets[k][5], sets[k][2], sets[k][3], n_threads=8)
+        assert np.abs(outs[k][0].cpu().numpy() - q_ref).max() < 1e-6 and np.array_equal(outs[k][1].cpu().numpy(), it_ref)

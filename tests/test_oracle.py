@@ -214,30 +214,67 @@ def test_work_item_semantics_chunk_equals_sequential_prefix():
 
 
 def test_verification_walk_equals_sequential():
-    """check_stride items (gmr_blob.h): chunks solved from a deliberately poor burn-in, then one walk per clip that adopts the
-    consistent chunks and re-solves the others -- the result is the sequential run, whatever the burn-in did."""
-    from gmr_amd.schedule import make_items as sched_items
+    """check_stride items (gmr_blob.h): chunks solved from a speculative start, then one walk per clip (schedule.plan_walks) that
+    adopts the consistent chunks and re-solves the others -- the result is the sequential run, whatever the speculation did.
+    Started from qpos0 at the world origin (INIT_QPOS0, a deliberately poor start with this short burn-in) some chunks are wrong
+    and get re-solved; started with the base on the root task's target (INIT_ROOT_TARGET, the default) fewer are."""
+    from gmr_amd._native import INIT_QPOS0, INIT_ROOT_TARGET
+    from gmr_amd.schedule import make_items as sched_items, plan_walks
     cm = compiled("smplx", "unitree_g1")
     orc = Oracle(cm.blob)
     pos, quat, names, offs, _ = synth.synth_clips(cm, 2, 90, seed=13, hard=True, dtype=np.float64)
     sc = cm.slot_columns(names)
     q_seq, it_seq, _ = orc.ik_solve(pos, quat, sc, make_items(offs, WORK_ITEM_DTYPE))
     chunk, burn = 8, 8
-    items = np.ascontiguousarray(sched_items(offs, chunk=chunk, burn_in=burn, track=True), dtype=WORK_ITEM_DTYPE)
-    n = len(items)
-    qf = np.zeros((2 * n, orc.nq))
-    q0, it0, _ = orc.ik_solve(pos, quat, sc, items, qpos_final=qf)
-    out_begin = items["frame_begin"] + items["n_burn"]
-    assert np.abs(q0 - q_seq).max() > 1e-3  # a short burn-in from qpos0 is not enough: the speculative chunks are wrong somewhere
-    walks = np.zeros(2, WORK_ITEM_DTYPE)
-    for c in range(2):
-        c0 = int(np.nonzero(out_begin == offs[c])[0][0])
-        walks[c] = (out_begin[c0 + 1], 0, int(offs[c + 1] - out_begin[c0 + 1]), c0, c0 + 1, n + c0 + 1, chunk)
-    q1, it1, _, done = orc.ik_solve(pos, quat, sc, walks, qpos_init=qf.copy(), qpos_final=qf, want_done=True)
-    solved = ~np.isnan(q1[:, 0])
-    q0[solved], it0[solved] = q1[solved], it1[solved]
-    assert np.abs(q0 - q_seq).max() < 1e-6 and np.array_equal(it0, it_seq)
-    assert 0 < done.sum() < 2 * 90 - 2 * chunk and int(solved.sum()) == int(done.sum())  # some chunks adopted, some re-solved
+    resolved = {}
+    for init in (INIT_QPOS0, INIT_ROOT_TARGET):
+        items = np.ascontiguousarray(sched_items(offs, chunk=chunk, burn_in=burn, track=True, chunk_init=init), dtype=WORK_ITEM_DTYPE)
+        assert set(items["init_row"]) == {INIT_QPOS0, init} and np.all(items["init_row"][items["n_burn"] == 0] == INIT_QPOS0)
+        n = len(items)
+        qf = np.zeros((2 * n, orc.nq))
+        q0, it0, _ = orc.ik_solve(pos, quat, sc, items, qpos_final=qf)
+        if init == INIT_QPOS0:
+            assert np.abs(q0 - q_seq).max() > 1e-3  # the speculative chunks are wrong somewhere
+        else:
+            assert np.abs(q0 - q_seq).max() < 1e-3  # every chunk already sits in the sequential run's basin
+        walks = np.ascontiguousarray(plan_walks(items, offs, chunk), dtype=WORK_ITEM_DTYPE)
+        assert len(walks) == 2 and np.all(walks["check_stride"] == chunk)
+        q1, it1, _, done = orc.ik_solve(pos, quat, sc, walks, qpos_init=qf.copy(), qpos_final=qf, want_done=True)
+        solved = ~np.isnan(q1[:, 0])
+        q0[solved], it0[solved] = q1[solved], it1[solved]
+        assert np.abs(q0 - q_seq).max() < 1e-6 and np.array_equal(it0, it_seq)
+        assert int(solved.sum()) == int(done.sum()) < 2 * 90 - 2 * chunk
+        resolved[init] = int(done.sum())
+    assert resolved[INIT_QPOS0] > 0 and resolved[INIT_ROOT_TARGET] <= resolved[INIT_QPOS0]
+
+
+def test_root_target_init_and_height_scale_items():
+    """The two per-item knobs of gmr_work_item (gmr_blob.h).  INIT_ROOT_TARGET: the first frame starts from qpos0 with the base on
+    the prepared root-task target.  height_scale: the item is solved with the scale table of a model compiled for that height."""
+    from gmr_amd._native import INIT_ROOT_TARGET
+    cm = compiled("smplx", "unitree_g1")
+    orc = Oracle(cm.blob)
+    pos, quat, names, offs, _ = synth.synth_clips(cm, 1, 12, seed=3, hard=True, dtype=np.float64)
+    sc = cm.slot_columns(names)
+    it = make_items([0, 12], WORK_ITEM_DTYPE)
+    it["frame_begin"], it["n_out"], it["init_row"] = 4, 8, INIT_ROOT_TARGET
+    q_a, _, _ = orc.ik_solve(pos, quat, sc, it)
+    tp, tq = orc.prepare_targets(pos[4][sc], quat[4][sc])
+    rt = [t for t in cm.tasks[0] if cm.robot.body_index(t.frame) == 0][0]
+    init = np.array(cm.robot.qpos0)
+    init[:3], init[3:7] = tp[cm.slot_names.index(rt.human)], tq[cm.slot_names.index(rt.human)]
+    it["init_row"] = 0
+    q_b, _, _ = orc.ik_solve(pos, quat, sc, it, qpos_init=init[None])
+    np.testing.assert_array_equal(q_a[4:], q_b[4:])
+    # height_scale 1.6 / 1.8 on the default model == a model compiled with actual_human_height = 1.6
+    cm16 = compiled("smplx", "unitree_g1", 1.6)
+    it = make_items([0, 12], WORK_ITEM_DTYPE)
+    it["height_scale"] = 1.6 / cm.config.human_height_assumption
+    q_s, n_s, _ = orc.ik_solve(pos, quat, sc, it)
+    q_m, n_m, _ = Oracle(cm16.blob).ik_solve(pos, quat, sc, make_items([0, 12], WORK_ITEM_DTYPE))
+    assert np.abs(q_s - q_m).max() < 1e-12 and np.array_equal(n_s, n_m)
+    q_1, _, _ = orc.ik_solve(pos, quat, sc, make_items([0, 12], WORK_ITEM_DTYPE))
+    assert np.abs(q_s - q_1).max() > 1e-3
 
 
 def test_offset_to_ground_and_height_ratio():
