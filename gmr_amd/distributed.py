@@ -95,3 +95,146 @@ def gather_rows(local_rows: torch.Tensor, lengths: Sequence[int]) -> torch.Tenso
             out[offs[i]:offs[i + 1]] = recv[r][cur:cur + lengths[i]]
             cur += lengths[i]
     return out.to(local_rows.device)
+
+
+# ------------------------------------------------------------------ few, long clips on several GPUs (BASELINE config 3)
+def _world():
+    return (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+
+
+def split_items(items: np.ndarray, world: int) -> List[tuple]:
+    """Contiguous ranges [lo, hi) of a chunk-item list, one per rank, balanced by frames processed (burn-in included)."""
+    cost = (items["n_burn"] + items["n_out"]).astype(np.int64)
+    cum = np.concatenate([[0], np.cumsum(cost)])
+    total = int(cum[-1])
+    cuts = [int(np.searchsorted(cum, total * r / world, side="left")) for r in range(world)] + [len(items)]
+    cuts = np.maximum.accumulate(np.minimum(cuts, len(items)))
+    return [(int(cuts[r]), int(cuts[r + 1])) for r in range(world)]
+
+
+def _allgather_ranges(t: torch.Tensor, ranges: Sequence[tuple]) -> None:
+    """In place: rank r holds valid rows ranges[r] = [lo, hi) of the full-size ``t``; afterwards every rank holds all of them."""
+    rank, world = _world()
+    if world == 1:
+        return
+    dev = _comm_device()
+    pad = max(hi - lo for lo, hi in ranges)
+    if pad == 0:
+        return
+    lo, hi = ranges[rank]
+    send = torch.zeros((pad,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+    send[: hi - lo] = t[lo:hi].to(dev)
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send)
+    for r, (a, b) in enumerate(ranges):
+        if r != rank and b > a:
+            t[a:b] = recv[r][: b - a].to(t.device)
+
+
+def solve_chunked_sharded(solve, n_frames: int, nq: int, seq_offsets, chunk: int, burn_in: int, device, height_scales=None):
+    """Verified parallel-in-time solve of a set of long clips with the chunks of EVERY clip spread over all ranks
+    (``Engine.ik_solve_chunked`` on one GPU; SURVEY 8(e) "contiguous time shards", BASELINE config 3).
+
+    Every rank holds the whole input (392 B/frame: a LAFAN1-sized set is ~160 MB) and calls this with the same arguments.
+    ``solve(items, qpos_init, qpos_final, out, iters, frames_done)`` runs work items on the rank's own device, writing into the
+    full-size buffers it is handed (``Engine.ik_solve`` bound to the inputs; the CPU oracle in the gloo test).
+
+    1. chunk items (``schedule.make_items(track=True)``) are split into contiguous ranges balanced by frames (``split_items``);
+       each rank solves its range: speculative chunk starts make the chunks independent of each other, so there is no
+       exchange inside this phase;
+    2. all-gather of what the chunks produced: qpos rows (288 B/frame), solve counts, and the per-chunk B / F states
+       (2 x 288 B per chunk) -- the one real exchange step of this path;
+    3. the verification walk of a clip runs on the clip's owner (``schedule.partition_clips``); walks only re-solve chunks
+       whose speculative start missed, and
+    4. those chunks' rows travel in a second, small all-gather (owner -> everyone); the re-solved-chunk mask is an all-reduce.
+
+    Returns (qpos [N, nq], iters [N], info) on every rank, equal to the sequential run to the walk's tolerance.
+    """
+    from . import _native
+    from .schedule import make_items, plan_walks
+    rank, world = _world()
+    offs = np.asarray(seq_offsets, dtype=np.int64)
+    items = make_items(offs, chunk=chunk, burn_in=burn_in, track=True, height_scales=height_scales)
+    n = len(items)
+    out = torch.full((n_frames, nq), float("nan"), dtype=torch.float64, device=device)
+    iters = torch.zeros(n_frames, dtype=torch.int32, device=device)
+    qf = torch.zeros((max(2 * n, 1), nq), dtype=torch.float64, device=device)
+    info = {"chunks": n, "resolved_frames": 0, "resolved_chunks": 0, "ranks": world}
+    if n == 0:
+        return out, iters, info
+    out_begin = (items["frame_begin"] + items["n_burn"]).astype(np.int64)
+    out_end = out_begin + items["n_out"]
+    ranges = split_items(items, world)
+    lo, hi = ranges[rank]
+    if hi > lo:
+        solve(items[lo:hi], None, qf, out, iters, None)
+    # -- exchange 1: chunk outputs and boundary states
+    frame_ranges = [(int(out_begin[a]), int(out_end[b - 1])) if b > a else (0, 0) for a, b in ranges]
+    _allgather_ranges(out, frame_ranges)
+    iv = iters.view(-1, 1)
+    _allgather_ranges(iv, frame_ranges)
+    _allgather_ranges(qf, ranges)                                        # F rows: row i of chunk i
+    _allgather_ranges(qf, [(n + a, n + b) for a, b in ranges])          # B rows: row n + i
+    # -- walks on the clips' owners
+    walks = plan_walks(items, offs, chunk)
+    if len(walks) == 0:
+        return out, iters, info
+    first_chunk = walks["init_row"].astype(np.int64)                     # (plan_walks: init_row = the clip's first chunk)
+    walk_len = walks["n_out"].astype(np.int64)
+    owner = np.zeros(len(walks), dtype=np.int64)
+    for r, part in enumerate(partition_clips(list(walk_len), world)):
+        owner[part] = r
+    mine = np.nonzero(owner == rank)[0]
+    resolved = torch.zeros(n, dtype=torch.int32, device=device)
+    if len(mine):
+        b_before = qf[n:2 * n].clone()
+        done = torch.zeros(len(mine), dtype=torch.int32, device=device)
+        solve(walks[mine], qf, qf, out, iters, done)
+        changed = (qf[n:2 * n] != b_before).any(dim=1)                    # a re-solved chunk got its B row rewritten (gmr_blob.h)
+        resolved = changed.to(torch.int32)
+        info["resolved_frames"] = int(done.sum().item())
+    if world > 1:
+        cdev = _comm_device()
+        rs = resolved.to(cdev)
+        dist.all_reduce(rs, op=dist.ReduceOp.MAX)
+        res_all = rs.cpu().numpy().astype(bool)
+        tot = torch.tensor([info["resolved_frames"]], dtype=torch.int64, device=cdev)
+        dist.all_reduce(tot)
+        info["resolved_frames"] = int(tot.item())
+        # -- exchange 2: rows of the re-solved chunks, owner -> everyone (chunk -> clip -> owner is known to all ranks)
+        chunk_owner = np.full(n, -1, dtype=np.int64)
+        nchunks = (walk_len + chunk - 1) // chunk
+        for k in range(len(walks)):
+            chunk_owner[first_chunk[k] + 1: first_chunk[k] + 1 + nchunks[k]] = owner[k]
+        idx = [np.nonzero(res_all & (chunk_owner == r))[0] for r in range(world)]
+        frames = [np.concatenate([np.arange(out_begin[c], out_end[c]) for c in ix]) if len(ix) else np.zeros(0, np.int64) for ix in idx]
+        pad_f, pad_c = max(len(f) for f in frames), max(len(ix) for ix in idx)
+        if pad_c > 0:
+            sendq = torch.zeros((pad_f, nq + 1), dtype=torch.float64, device=cdev)
+            sends = torch.zeros((pad_c, 2 * nq), dtype=torch.float64, device=cdev)
+            fi = torch.from_numpy(frames[rank]).to(device)
+            ci = torch.from_numpy(idx[rank]).to(device)
+            if len(frames[rank]):
+                sendq[: len(fi), :nq] = out[fi].to(cdev)
+                sendq[: len(fi), nq] = iters[fi].to(torch.float64).to(cdev)   # (solve counts < 2^31: exact in float64)
+                sends[: len(ci), :nq] = qf[ci].to(cdev)
+                sends[: len(ci), nq:] = qf[n + ci].to(cdev)
+            rq = [torch.empty_like(sendq) for _ in range(world)]
+            rsb = [torch.empty_like(sends) for _ in range(world)]
+            dist.all_gather(rq, sendq)
+            dist.all_gather(rsb, sends)
+            for r in range(world):
+                if r == rank or len(idx[r]) == 0:
+                    continue
+                fr = torch.from_numpy(frames[r]).to(device)
+                cr = torch.from_numpy(idx[r]).to(device)
+                blk = rq[r][: len(fr)].to(device)
+                out[fr] = blk[:, :nq]
+                iters[fr] = blk[:, nq].to(torch.int32)
+                sb = rsb[r][: len(cr)].to(device)
+                qf[cr] = sb[:, :nq]
+                qf[n + cr] = sb[:, nq:]
+        info["resolved_chunks"] = int(res_all.sum())
+    else:
+        info["resolved_chunks"] = int(resolved.sum().item())
+    return out, iters, info

@@ -160,6 +160,20 @@ class Engine:
             info["passes"] = 1
         return out, iters, info
 
+    def ik_solve_chunked_sharded(self, pos: torch.Tensor, quat: torch.Tensor, slot_col: np.ndarray, seq_offsets, chunk: int, burn_in: int,
+                                 params: Optional[IKParams] = None, eps: float = 1e-7, height_scales=None):
+        """``ik_solve_chunked`` with the chunks of every clip spread over all ranks of the default process group
+        (``distributed.solve_chunked_sharded``: BASELINE config 3, few long clips on several GPUs).  Every rank passes the
+        same full inputs and receives the full result."""
+        from .distributed import solve_chunked_sharded
+        prm = params or IKParams()
+        prm = IKParams(prm.damping, prm.tol, prm.limit_gain, prm.lm_damping, prm.max_iter, prm.offset_to_ground, eps)
+
+        def solve(items, qinit, qfinal, out, iters, done):
+            self.ik_solve(pos, quat, slot_col, items, params=prm, qpos_init=qinit, qpos_final=qfinal, out=out, iters=iters, frames_done=done)
+
+        return solve_chunked_sharded(solve, int(pos.shape[0]), self.nq, seq_offsets, chunk, burn_in, self.device, height_scales=height_scales)
+
     def evaluate(self, qpos: torch.Tensor, pos: Optional[torch.Tensor] = None, quat: Optional[torch.Tensor] = None,
                  slot_col: Optional[np.ndarray] = None, offset_to_ground: bool = False, want_errors: bool = True, want_poses: bool = False,
                  height_scale: Optional[torch.Tensor] = None, want_task_errors: bool = False):

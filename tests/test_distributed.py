@@ -54,3 +54,66 @@ def test_broadcast_shard_gather_world2():
     assert sorted(res[0][2] + res[1][2]) == list(range(len(lengths)))
     loads = [sum(lengths[i] for i in r[2]) for r in res]
     assert abs(loads[0] - loads[1]) <= max(lengths)
+
+
+def _oracle_solver(orc, pos, quat, sc):
+    """The ``solve`` callable of solve_chunked_sharded backed by the CPU oracle's work-item restatement."""
+    def solve(items, qinit, qfinal, out, iters, done):
+        qo, it, _, dn = orc.ik_solve(pos, quat, sc, items, qpos_init=None if qinit is None else qinit.numpy().copy(),
+                                     qpos_final=qfinal.numpy(), want_done=True)
+        m = ~np.isnan(qo[:, 0])
+        out.numpy()[m] = qo[m]
+        iters.numpy()[m] = it[m]
+        if done is not None:
+            done.numpy()[:] = dn
+    return solve
+
+
+def _chunk_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from gmr_amd import distributed as gdist, synth
+    from gmr_amd._native import INIT_QPOS0
+    from gmr_amd.schedule import make_items
+    from oracle.oracle import Oracle
+    gdist.init_from_env(backend="gloo")
+    cm = compiled("smplx", "unitree_g1")
+    orc = Oracle(cm.blob)
+    lengths = [150, 37, 96]
+    pos, quat, names, _, _ = synth.synth_clips(cm, 1, sum(lengths), seed=5, hard=True, dtype=np.float32)
+    offs = np.concatenate([[0], np.cumsum(lengths)])
+    sc = cm.slot_columns(names)
+    heights = [1.0, 0.93, 1.05]
+    solve = _oracle_solver(orc, pos, quat, sc)
+    out, iters, info = gdist.solve_chunked_sharded(solve, int(offs[-1]), orc.nq, offs, 8, 6, torch.device("cpu"), height_scales=heights)
+    q_seq, it_seq, _ = orc.ik_solve(pos, quat, sc, make_items(offs, height_scales=heights))
+    ok = bool(np.abs(out.numpy() - q_seq).max() < 1e-6 and np.array_equal(iters.numpy(), it_seq))
+    # the same from deliberately poor starts: more chunks must travel in the second exchange
+    import gmr_amd.schedule as sched
+    orig = sched.make_items
+    sched.make_items = lambda *a, **k: orig(*a, **{**k, "chunk_init": INIT_QPOS0})
+    out2, iters2, info2 = gdist.solve_chunked_sharded(solve, int(offs[-1]), orc.nq, offs, 8, 2, torch.device("cpu"), height_scales=heights)
+    sched.make_items = orig
+    ok2 = bool(np.abs(out2.numpy() - q_seq).max() < 1e-6 and np.array_equal(iters2.numpy(), it_seq))
+    q.put((rank, ok, ok2, info, info2))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_long_clips_chunks_sharded_world2():
+    """BASELINE config 3 on N ranks (world 2, gloo, the oracle's work items as the per-rank solver): chunks of every clip spread
+    over both ranks, boundary states and rows all-gathered, walks on the clips' owners, re-solved chunks sent back -- every rank
+    ends with the sequential result (values and solve counts), also when the speculative starts are poor."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chunk_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] and r[2] for r in res), res
+    assert res[0][3] == res[1][3] and res[0][4] == res[1][4]           # both ranks agree on what was re-solved
+    assert res[0][3]["ranks"] == 2 and res[0][4]["resolved_chunks"] > res[0][3]["resolved_chunks"] >= 0
+    assert res[0][4]["resolved_frames"] > 0

@@ -468,11 +468,9 @@ def test_verification_walk_matches_oracle():
     chunk, burn = 8, 8
     items = make_items(offs, chunk=chunk, burn_in=burn, track=True)
     n = len(items)
-    ob = items["frame_begin"] + items["n_burn"]
-    walks = np.zeros(3, W)
-    for c in range(3):
-        c0 = int(np.nonzero(ob == offs[c])[0][0])
-        walks[c] = (ob[c0 + 1], 0, int(offs[c + 1] - ob[c0 + 1]), c0, c0 + 1, n + c0 + 1, chunk)
+    from gmr_amd.schedule import plan_walks
+    walks = plan_walks(items, offs, chunk)
+    assert len(walks) == 3
     # oracle
     qf_o = np.zeros((2 * n, orc.nq))
     q_o, it_o, _ = orc.ik_solve(pos, quat, sc, items, qpos_final=qf_o)
