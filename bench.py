@@ -5,15 +5,21 @@
 
 A "step" is one pass of the hot path (two-stage box-constrained IK of every frame, warm start carried
 along each clip exactly as the reference's caller loop does) over one batch of synthetic AMASS-shaped
-clips already resident in HBM.  N > 1 is launched one rank per GPU by torch.distributed.run; clips are
-independent so ranks own disjoint clips and there is no collective inside the timed region (weak
+clips already resident in HBM.  N > 1 runs one rank per GPU: under torch.distributed.run (the driver's
+launch) the ranks are already there; a bare ``python bench.py --gpus N`` starts them itself (a child
+torch.distributed.run, spawned before this process touches the GPU) and relays rank 0's line.  Clips are
+independent, so ranks own disjoint clips and there is no collective inside the timed region (weak
 scaling: S clips per GPU); rank 0 broadcasts the packed model once before it.
 
 One JSON line on stdout (rank 0).  Besides the driver's contract it carries
-  roofline      dominant kernel (ik_kernel) vs the HBM roofline: algorithmic bytes / kernel time (HIP events)
-  valu          the same kernel vs the FP64 vector peak, with the measured solves/frame
-  cpu_baseline  oracle/ (float64 C restatement of the reference algorithm) timed on this host's cores
-  parity        max |qpos_gpu - qpos_cpu| on the clips the CPU leg solved
+  value_unshaped  the same metric on the un-shaped workload: every clip distinct, any initial heading, variable lengths
+  roofline        dominant kernel (ik_kernel) vs the bound that binds it, FP64 vector issue: SURVEY 8(d)'s flop per solve x
+                  measured solves, over the kernel time from HIP events; `hbm` is the same kernel against the HBM roofline
+                  (north_star asks for it; ~0.3 % by construction, not the bound)
+  fk, dataset_path, host_fed, single_clip, long_clips, live_session   the other kernels / modes of the path (N = 1)
+  collectives, strong, long_clips_sharded                             N > 1: RCCL exchange steps timed on the real outputs
+  cpu_baseline    oracle/ (float64 C restatement of the reference algorithm) timed on this host's cores
+  parity          max |qpos_gpu - qpos_cpu| on the clips the CPU leg solved (both workloads)
 The CPU oracle is used here only as checker / comparator; the timed GPU path never touches it.
 """
 from __future__ import annotations
@@ -21,30 +27,72 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-from gmr_amd import distributed as gdist  # noqa: E402
-from gmr_amd import params, synth  # noqa: E402
-from gmr_amd.engine import Engine  # noqa: E402
-from gmr_amd.ik_config import load_ik_config  # noqa: E402
-from gmr_amd.mjcf import load_robot  # noqa: E402
-from gmr_amd.model import compile_model  # noqa: E402
-from gmr_amd.schedule import make_items  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VECTOR_PEAK_TF = 78.6  # AMD MI355X datasheet; = 1/2 of the guide's 157.3 TF FP32 (packed) vector peak
 ROBOT, SRC = "unitree_g1", "smplx"
 
+# HBM bytes per output frame of ik_kernel measured with rocprofv3 PMC passes (profiles/r01_v17_pmc_*: 2 x FETCH_SIZE
+# (gfx950 counts half, MI355X_MICROARCH.md "HBM") + WRITE_SIZE over an 8192 x 600 = 4.9152e6-frame launch):
+# 1.93 GB read + 1.44 GB written = 685 B/frame (393 + 292) against 684 algorithmic.  Valid for THIS configuration only
+# (unitree_g1 / smplx / float32 key-points); any other launch reports its algorithmic bytes and says so.
+MEASURED_TRAFFIC = {"robot": "unitree_g1", "src": "smplx", "in_itemsize": 4,
+                    "bytes_per_frame": (2 * 942730.6 * 1024 + 1401605.1 * 1024) / 4915200.0, "source": "profiles/r01_v17_pmc_*"}
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--clips", type=int, default=8192, help="clips per GPU (AMASS holds >1e4 sequences; several clips per wavefront slot -- 2048 slots on a MI355X -- let the hardware dispatcher balance clips that need more solves than others)")
+    ap.add_argument("--frames", type=int, default=3000, help="frames per clip (one AMASS sequence ~3k frames @30fps)")
+    ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic clips of the shaped workload, tiled to --clips")
+    ap.add_argument("--cpu-clips", type=int, default=0, help="clips solved by the CPU oracle per workload (baseline + parity); 0 = 4 per host core, capped at 512")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-unshaped", action="store_true", help="skip the un-shaped workload (value_unshaped)")
+    ap.add_argument("--hot-only", action="store_true", help="only the warmup + timed launches of the headline workload (no other legs): the "
+                    "form profiled under rocprofv3 so the kernel's average duration is that of the timed launch")
+    ap.add_argument("--hot-fk", action="store_true", help="with --hot-only: also run the timed fk_kernel launches (profiles/r02_fk_*)")
+    return ap.parse_args(argv)
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks as a child torch.distributed.run and relay rank 0's line.
+    Runs before this process has imported torch or touched the GPU; the parent never initialises HIP (no exec either)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:
+        ln = ln.rstrip("\n")
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        elif ln:
+            print(ln, file=sys.stderr)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    return rc if rc != 0 else (0 if line is not None else 1)
+
 
 def flops_per_solve(cm) -> float:
     """algorithmic flop per (frame, solve), sparse-Jacobian convention, mean over the two tables."""
+    import numpy as np
     rob = cm.robot
     nb, nv = rob.nbody, rob.nv
     out = []
@@ -75,30 +123,25 @@ def host_cores() -> int:
     return max(1, n)
 
 
-# HBM bytes per output frame of ik_kernel measured with rocprofv3 PMC passes (profiles/r01_v17_pmc_*: 2 x FETCH_SIZE
-# (gfx950 counts half, MI355X_MICROARCH.md "HBM") + WRITE_SIZE over an 8192 x 600 = 4.9152e6-frame launch):
-# 1.93 GB read + 1.44 GB written = 685 B/frame (393 + 292) against 684 algorithmic.
-MEASURED_TRAFFIC_BYTES_PER_FRAME = (2 * 942730.6 * 1024 + 1401605.1 * 1024) / 4915200.0
-
-
 def bytes_per_frame(cm, in_itemsize=4) -> int:
     """Compulsory HBM traffic of the IK kernel per output frame: key-points in, qpos (f64) + solve count out."""
     return cm.nslot * 7 * in_itemsize + cm.robot.nq * 8 + 4
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--clips", type=int, default=8192, help="clips per GPU (AMASS holds >1e4 sequences; several clips per wavefront slot -- 2048 slots on a MI355X -- let the hardware dispatcher balance clips that need more solves than others)")
-    ap.add_argument("--frames", type=int, default=3000, help="frames per clip (one AMASS sequence ~3k frames @30fps)")
-    ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic clips generated, tiled to --clips")
-    ap.add_argument("--cpu-clips", type=int, default=0, help="clips solved by the CPU oracle (baseline + parity); 0 = 2 per host core, capped at 512")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--hot-only", action="store_true", help="only the warmup + timed launches (no single-clip / CPU legs): the "
-                    "form profiled under rocprofv3 so the kernel's average duration is that of the timed launch")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+
+    import numpy as np
+    import torch
+
+    from gmr_amd import distributed as gdist
+    from gmr_amd import GeneralMotionRetargeting, params, synth
+    from gmr_amd.ik_config import load_ik_config
+    from gmr_amd.mjcf import load_robot
+    from gmr_amd.model import compile_model
+    from gmr_amd.schedule import make_items
 
     # Rehearsal of the N > 1 path on a single-GPU box: GMR_BENCH_BACKEND=gloo GMR_BENCH_SHARE_GPU=1 runs every rank on cuda:0
     # with CPU collectives (everything but RCCL itself); the real run uses the defaults (nccl = RCCL, one GPU per rank).
@@ -107,7 +150,7 @@ def main():
         local = 0
     on_rccl = world > 1 and torch.distributed.get_backend() == "nccl"
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the engine has no CPU path)")
     torch.cuda.set_device(local)
@@ -117,11 +160,51 @@ def main():
     cm = compile_model(load_robot(params.ROBOT_XML_DICT[ROBOT], name=ROBOT), load_ik_config(params.IK_CONFIG_DICT[SRC][ROBOT]))
     blob = gdist.broadcast_blob(cm.blob if rank == 0 else None)
     assert blob == cm.blob, "packed model differs between ranks"
-    eng = Engine(cm, local)
+    gmr = GeneralMotionRetargeting(SRC, ROBOT, device=local)
+    eng = gmr._engine
+    assert gmr._cm.blob == cm.blob
+    kernel_name = f"gmr::ik_kernel<{eng.info.nv_padded}, {'true' if eng.info.reserved[0] else 'false'}>"
 
-    # ---- synthetic AMASS-shaped batch, resident in HBM.  Every rank builds the same batch (same seeds): weak scaling with
-    #      identical work per GPU, as synthetic-data benchmarks usually do; with per-rank seeds the slowest rank's random draw of
-    #      clips would set the time ----
+    def barrier():
+        if world > 1:
+            if on_rccl:
+                torch.distributed.barrier(device_ids=[local])  # RCCL: the barrier runs on this rank's own GPU
+            else:
+                torch.distributed.barrier()
+
+    def max_over_ranks(x: float) -> float:
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev if on_rccl else "cpu")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed_steps(fn, steps, warmup):
+        """The driver's protocol: W untimed, then EXACTLY K steps between barrier + synchronize, max over ranks; the kernel time
+        from HIP events on the launch stream."""
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        barrier()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        r = None
+        for k in range(steps):
+            ev[k][0].record()
+            r = fn()
+            ev[k][1].record()
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        return elapsed, float(np.mean([a.elapsed_time(b) for a, b in ev])), r
+
+    def solve_stats(iters):
+        it = iters & 0x3FFFFFFF
+        return (float(it.to(torch.float64).mean().item()),
+                torch.bincount(it.flatten().to(torch.int64), minlength=23)[:23].cpu().tolist(), int((iters >> 30).ne(0).sum().item()))
+
+    # ---- workload 1 (headline, as in round 1): S clips x T frames per GPU, D distinct clips tiled, initial heading within 1 rad.
+    #      Every rank builds the same batch (same seeds): weak scaling with identical work per GPU ----
     S, T, D = args.clips, args.frames, min(args.distinct, args.clips)
     pe, qe, names, _, _ = synth.synth_clips(cm, D // 2, T, seed=1000, hard=False, dtype=np.float32)
     ph, qh, _, _, _ = synth.synth_clips(cm, D - D // 2, T, seed=2000, hard=True, dtype=np.float32)
@@ -135,148 +218,291 @@ def main():
     out = torch.empty((S * T, eng.nq), dtype=torch.float64, device=dev)
     n_frames = S * T
 
-    def step():
-        return eng.ik_solve(pos, quat, sc, items, out=out)
-
-    def barrier():
-        if world > 1:
-            if on_rccl:
-                torch.distributed.barrier(device_ids=[local])  # RCCL: the barrier runs on this rank's own GPU
-            else:
-                torch.distributed.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    iters = None
-    for k in range(args.steps):
-        ev[k][0].record()
-        _, iters, _ = step()
-        ev[k][1].record()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if on_rccl else "cpu")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    it = (iters & 0x3FFFFFFF).to(torch.float64)
-    mean_solves = float(it.mean().item())
-    solves_hist = torch.bincount((iters & 0x3FFFFFFF).flatten().to(torch.int64), minlength=23)[:23].cpu().tolist()
-    qp_capped = int((iters >> 30).sum().item())
+    elapsed, kern_ms, (_, iters, _) = timed_steps(lambda: eng.ik_solve(pos, quat, sc, items, out=out), args.steps, args.warmup)
+    mean_solves, solves_hist, qp_capped = solve_stats(iters)
     if torch.isnan(out).any().item():
         raise SystemExit("non-finite qpos in the benchmark output")
+
+    # ---- workload 2 (un-shaped): every clip distinct, initial heading anywhere in (-pi, pi], lengths U(T/3, 5T/3), half the clips
+    #      noisy / over-reaching; generated on the GPU (gmr_amd.synth.synth_clips_torch) ----
+    un = None
+    if not args.no_unshaped and not args.hot_only:
+        rng = np.random.default_rng(7)
+        lens = rng.integers(max(1, T // 3), max(2, 5 * T // 3) + 1, size=S)
+        hard_mask = np.arange(S) % 2 == 1
+        t_gen = time.perf_counter()
+        upos, uquat, unames, uoffs = synth.synth_clips_torch(cm, lens, seed=4242, device=dev, hard=hard_mask, yaw0=np.pi)
+        torch.cuda.synchronize()
+        t_gen = time.perf_counter() - t_gen
+        uitems = make_items(uoffs)
+        usc = cm.slot_columns(unames)
+        uout = torch.empty((int(uoffs[-1]), eng.nq), dtype=torch.float64, device=dev)
+        u_el, u_kern_ms, (_, uiters, _) = timed_steps(lambda: eng.ik_solve(upos, uquat, usc, uitems, out=uout), max(1, args.steps - 1), 1)
+        u_solves, u_hist, u_capped = solve_stats(uiters)
+        if torch.isnan(uout).any().item():
+            raise SystemExit("non-finite qpos in the un-shaped benchmark output")
+        un = {"frames": int(uoffs[-1]), "elapsed": u_el, "steps": max(1, args.steps - 1), "kern_ms": u_kern_ms, "solves": u_solves, "hist": u_hist,
+              "capped": u_capped, "gen_s": t_gen, "lens": lens}
 
     result = None
     if rank == 0:
         total_frames = n_frames * world * args.steps
         value = total_frames / elapsed
-        bpf, fps_kernel = bytes_per_frame(cm), n_frames / (kern_ms * 1e-3)
+        in_sz = pos.element_size()
+        bpf, fps_kernel = bytes_per_frame(cm, in_sz), n_frames / (kern_ms * 1e-3)
         ach_gbs = bpf * fps_kernel / 1e9
         fsolve = flops_per_solve(cm)
         ach_tf = fps_kernel * mean_solves * fsolve / 1e12
+        measured = (MEASURED_TRAFFIC["robot"], MEASURED_TRAFFIC["src"], MEASURED_TRAFFIC["in_itemsize"]) == (ROBOT, SRC, in_sz)
+        traffic = (MEASURED_TRAFFIC["bytes_per_frame"] if measured else bpf) * n_frames
         result = {
             "metric": "retargeted frames/sec (whole node), Unitree G1 29-DoF SMPLX; max qpos err vs CPU",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": f"AMASS-shaped smplx->unitree_g1 (29 DoF, nq 36): {S} clips x {T} frames @30fps per GPU "
-                            f"({D} distinct: half exactly reachable, half 2cm/5deg noise + 1.1x arm reach), frames sequential per clip "
-                            "(exact reference warm-start semantics), clips independent",
+                "workload": f"AMASS-shaped smplx->unitree_g1 (29 DoF, nq 36): {S} clips x {T} frames @30fps per GPU, equal lengths, "
+                            f"{D} distinct clips tiled (half exactly reachable, half 2cm/5deg noise + 1.1x arm reach), initial heading within "
+                            "1 rad of the robot's; frames sequential per clip (exact reference warm-start semantics), clips independent.  "
+                            "value_unshaped: same size, every clip distinct, heading in (-pi, pi], lengths U(T/3, 5T/3), same easy/hard mix",
                 "clips_per_gpu": S, "frames_per_clip": T, "frames_per_step": n_frames * world, "parallelism": f"clip-sharded x{world}",
+                "distinct_clips": D, "initial_heading_rad": 1.0,
             },
-            "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
-                         "traffic": MEASURED_TRAFFIC_BYTES_PER_FRAME * n_frames, "traffic_source": "profiles/r01_v17_pmc_* scaled to this launch", "kernel": f"gmr::ik_kernel<{eng.info.nv_padded}, {'true' if eng.info.reserved[0] else 'false'}>", "kernel_ms": kern_ms, "bytes_per_frame": bpf},
-            "valu": {"bound": "fp64-vector", "achieved": ach_tf, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": ach_tf / FP64_VECTOR_PEAK_TF,
-                     "flop_per_solve": fsolve, "mean_solves_per_frame": mean_solves,
-                     "solves_per_frame_histogram": solves_hist},
+            "roofline": {"bound": "fp64-vector", "achieved": ach_tf, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": ach_tf / FP64_VECTOR_PEAK_TF,
+                         "traffic": traffic, "traffic_source": (MEASURED_TRAFFIC["source"] + " (PMC, this configuration) scaled to this launch")
+                         if measured else "algorithmic bytes (no PMC pass for this configuration)",
+                         "kernel": kernel_name, "kernel_ms": kern_ms, "flop_per_solve": fsolve, "mean_solves_per_frame": mean_solves,
+                         "solves_per_frame_histogram": solves_hist,
+                         "note": "achieved = SURVEY 8(d) flop/solve x measured solves/frame x frames / kernel time (HIP events)"},
+            "hbm": {"bound": "hbm", "non_binding": True, "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
+                    "bytes_per_frame": bpf},
             "qp_iteration_caps_hit": qp_capped,
         }
-        if world == 1 and not args.hot_only:
-            # BASELINE config 2 taken literally: ONE 3000-frame clip on one GPU, parallel-in-time chunks with verified
-            # boundaries (Engine.ik_solve_chunked) vs the same clip solved sequentially by one wavefront.
-            one_p, one_q, one_offs = pos[:T].contiguous(), quat[:T].contiguous(), offs[:2]
-            def timed(fn, reps=5):
-                ts = []
-                for _ in range(reps):
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    r = fn()
-                    torch.cuda.synchronize()
-                    ts.append(time.perf_counter() - t1)
-                return float(np.median(ts)), r
-            t_seq, (q_seq, _, _) = timed(lambda: eng.ik_solve(one_p, one_q, sc, make_items(one_offs)), reps=3)
-            t_chk, (q_chk, _, info) = timed(lambda: eng.ik_solve_chunked(one_p, one_q, sc, one_offs, chunk=16, burn_in=24))
-            # live single-sequence mode (gmr_session_*): host frame in -> host qpos out, one launch per frame
-            ses = eng.session(sc, int(one_p.shape[1]), dtype=np.float32)
-            hp, hq = one_p[:256].cpu().numpy(), one_q[:256].cpu().numpy()
-            lat = []
-            for i in range(256):
+        if un is not None:
+            result["value_unshaped"] = un["frames"] * world * un["steps"] / un["elapsed"]
+            result["unshaped"] = {
+                "frames_per_gpu": un["frames"], "clips_per_gpu": S, "steps": un["steps"], "ms_per_step": 1e3 * un["elapsed"] / un["steps"], "kernel_ms": un["kern_ms"],
+                "mean_solves_per_frame": un["solves"], "solves_per_frame_histogram": un["hist"], "qp_iteration_caps_hit": un["capped"],
+                "clip_length_min_max": [int(un["lens"].min()), int(un["lens"].max())], "generation_s": un["gen_s"],
+                "valu_frac": un["frames"] / (un["kern_ms"] * 1e-3) * un["solves"] * fsolve / 1e12 / FP64_VECTOR_PEAK_TF,
+            }
+
+    # ------------------------------------------------------------------ N > 1: the exchange steps, on the real outputs
+    if world > 1 and not args.hot_only:
+        cdev = dev if on_rccl else torch.device("cpu")
+        ones = torch.ones(1, dtype=torch.float64, device=cdev)
+        torch.distributed.all_reduce(ones)
+        # all-gather of qpos (north_star: "allgather of qpos over xGMI"): a bounded sample of this rank's output rows
+        ns_clips = min(S, 1024)
+        lengths = [T] * (ns_clips * world)
+        mine = gdist.my_clips(lengths)
+        local_rows = out[: len(mine) * T]
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        full = gdist.gather_rows(local_rows, lengths)
+        torch.cuda.synchronize()
+        barrier()
+        t_ag = max_over_ranks(time.perf_counter() - t0)
+        ok_rows = bool(full.shape[0] == ns_clips * world * T)
+        del full
+        # strong scaling: the SAME S clips split over the ranks (longest-first greedy; equal lengths -> S / world each)
+        s_mine = gdist.my_clips([T] * S)
+        s_items = make_items(np.arange(len(s_mine) + 1, dtype=np.int64) * T)
+        n_s = len(s_mine) * T
+        st_el, _, _ = timed_steps(lambda: eng.ik_solve(pos[:n_s], quat[:n_s], sc, s_items, out=out[:n_s]), args.steps, 1)
+        # few long clips (BASELINE config 3): a LAFAN1-sized set, chunks of every clip spread over all ranks
+        lc = long_clip_set(cm, synth, dev)
+        lc_el, _, (q_lc, _, lc_info) = timed_steps(lambda: lc["eng"].ik_solve_chunked_sharded(lc["pos"], lc["quat"], lc["sc"], lc["offs"], 64, 32), 2, 1)
+        if rank == 0:
+            result["collectives"] = {
+                "backend": torch.distributed.get_backend(), "rccl_ranks": int(ones.item()),
+                "allgather_qpos_ms": 1e3 * t_ag, "allgather_rows_per_rank": int(local_rows.shape[0]), "allgather_bytes_per_rank": int(local_rows.shape[0]) * eng.nq * 8,
+                "allgather_GBps_received_per_rank": int(local_rows.shape[0]) * eng.nq * 8 * (world - 1) / t_ag / 1e9, "allgather_complete": ok_rows,
+                "note": f"gather_rows of {ns_clips} clips x {T} frames of real output per rank (288 B/frame) to every rank; outside the timed region of `value`",
+            }
+            result["strong"] = {"clips_total": S, "frames_per_step": S * T, "value": S * T * args.steps / st_el, "ms_per_step": 1e3 * st_el / args.steps}
+            result["long_clips_sharded"] = {"clips": len(lc["offs"]) - 1, "frames": int(lc["offs"][-1]), "frames_per_s": 2 * int(lc["offs"][-1]) / lc_el,
+                                            "chunk": 64, "burn_in": 32, **{k: lc_info[k] for k in ("chunks", "resolved_frames", "resolved_chunks", "ranks")}}
+
+    # ------------------------------------------------------------------ N = 1: the other kernels and modes of the path
+    if rank == 0 and world == 1 and (not args.hot_only or args.hot_fk):
+        # fk_kernel (KinematicsModel.forward_kinematics): HBM-bound; positions only, as the dataset path calls it
+        nf = n_frames
+        root_pos32 = out[:, 0:3].to(torch.float32).contiguous()
+        root_rot32 = out[:, [4, 5, 6, 3]].to(torch.float32).contiguous()
+        dof32 = out[:, 7:].to(torch.float32).contiguous()
+        fk_el, fk_ms, _ = timed_steps(lambda: eng.fk(root_pos32, root_rot32, dof32, want_rot=False), 3, 1)
+        fk_bytes = (7 + eng.nq - 7) * 4 + eng.nbody * 12
+        fk_el2, fk_ms2, _ = timed_steps(lambda: eng.fk(root_pos32[: nf // 2], root_rot32[: nf // 2], dof32[: nf // 2], want_rot=True), 3, 1)
+        fk_bytes2 = fk_bytes + eng.nbody * 16
+        result["fk"] = {
+            "kernel": "gmr::fk_kernel<0>", "frames": nf, "kernel_ms": fk_ms, "frames_per_s": nf / (fk_ms * 1e-3),
+            "roofline": {"bound": "hbm", "achieved": fk_bytes * nf / (fk_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": fk_bytes * nf / (fk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_frame": fk_bytes, "traffic": None},
+            "with_rotations": {"frames": nf // 2, "kernel_ms": fk_ms2, "bytes_per_frame": fk_bytes2,
+                               "frac": fk_bytes2 * (nf // 2) / (fk_ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        }
+        del root_pos32, root_rot32, dof32
+    if rank == 0 and world == 1 and not args.hot_only:
+        from gmr_amd import dataset
+
+        def timed(fn, reps=5):
+            ts = []
+            r = None
+            for _ in range(reps):
+                torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                ses.step(hp[i], hq[i])
-                lat.append(time.perf_counter() - t1)
-            ses.close()
-            lat = np.array(lat[16:]) * 1e6
-            result["live_session"] = {"frames": int(lat.size), "median_latency_us": float(np.median(lat)), "p99_latency_us": float(np.quantile(lat, 0.99)),
-                                      "frames_per_s": float(1e6 / lat.mean()), "includes": "host staging + launch + kernel + sync, one wavefront"}
-            # the same path fed from / returned to pageable host arrays (what retarget_batch does for numpy callers): PCIe inclusive
-            nh = min(S, 512) * T
-            hp_all, hq_all = pos[:nh].cpu().numpy(), quat[:nh].cpu().numpy()
-            h_items = make_items(offs[: nh // T + 1])
-            def host_fed():
-                q_h, _, _ = eng.ik_solve(torch.from_numpy(hp_all).to(dev), torch.from_numpy(hq_all).to(dev), sc, h_items, want_iters=False)
-                return q_h.cpu().numpy()
-            t_host, _ = timed(host_fed, reps=3)
-            result["host_fed"] = {"frames": nh, "frames_per_s": nh / t_host, "includes": "H2D of the key-points (392 B/frame) + kernel + D2H of qpos (288 B/frame), pageable host memory, no overlap"}
-            result["single_clip"] = {
-                "frames": T, "sequential_frames_per_s": T / t_seq, "verified_chunked_frames_per_s": T / t_chk,
-                "chunk": 16, "burn_in": 24, "passes": info["passes"], "resolved_frames": info["resolved_frames"],
-                "max_abs_diff_vs_sequential": float((q_chk - q_seq).abs().max().item()), "includes": "host scheduling + verification passes",
-            }
-        if world == 1 and not args.no_cpu and not args.hot_only:
-            from oracle.oracle import Oracle  # checker / comparator only
-            orc = Oracle(cm.blob)
-            cores = host_cores()
-            nc = min(args.cpu_clips if args.cpu_clips > 0 else min(512, max(32, 4 * cores)), S)
-            cp, cq = pos[: nc * T].cpu().numpy(), quat[: nc * T].cpu().numpy()
-            citems = make_items(offs[: nc + 1])
-            one = 4
+                r = fn()
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t1)
+            return float(np.median(ts)), r
+
+        # the dataset path of scripts/smplx_to_robot_dataset.py:79-146 on resident key-points: IK + FK (local) + FK min-height +
+        # post-processing, to host arrays ready for pickling (pickle / disk excluded)
+        nd = min(S, 2048)
+        t_dev, _ = timed(lambda: _dataset_device(gmr, dataset, pos[: nd * T], quat[: nd * T], names, offs[: nd + 1]), reps=3)
+        t_all, _ = timed(lambda: dataset.retarget_clips(gmr, pos[: nd * T], quat[: nd * T], names, offs[: nd + 1]), reps=2)
+        result["dataset_path"] = {"clips": nd, "frames": nd * T, "frames_per_s_device": nd * T / t_dev, "frames_per_s_to_host": nd * T / t_all,
+                                  "includes": "ik_kernel + fk_kernel (local_body_pos) + fk min-height + root adjustments; `to_host` adds the D2H of "
+                                              "root_pos / root_rot / dof_pos (f64) + local_body_pos (f32, 456 B/frame) into pageable arrays"}
+        # BASELINE config 2 taken literally: ONE 3000-frame clip on one GPU, parallel-in-time chunks with verified
+        # boundaries (Engine.ik_solve_chunked) vs the same clip solved sequentially by one wavefront; an easy and a hard clip
+        sclip = {}
+        for label, c in (("easy", 0), ("hard", D // 2)):
+            one_p, one_q, one_offs = pos[c * T:(c + 1) * T].contiguous(), quat[c * T:(c + 1) * T].contiguous(), offs[:2]
+            t_seq, (q_seq, it_seq, _) = timed(lambda: eng.ik_solve(one_p, one_q, sc, make_items(one_offs)), reps=3)
+            t_chk, (q_chk, it_chk, info) = timed(lambda: eng.ik_solve_chunked(one_p, one_q, sc, one_offs, chunk=16, burn_in=24))
+            sclip[label] = {"sequential_frames_per_s": T / t_seq, "verified_chunked_frames_per_s": T / t_chk, "resolved_frames": info["resolved_frames"],
+                            "max_abs_diff_vs_sequential": float((q_chk - q_seq).abs().max().item()),
+                            "frames_with_different_solve_count": int((it_chk != it_seq).sum().item())}
+        result["single_clip"] = {"frames": T, "chunk": 16, "burn_in": 24, "chunk_start": "root-task target (GMR_INIT_ROOT_TARGET)", **sclip,
+                                 "includes": "host scheduling + both launches (chunks, verification walk)"}
+        # BASELINE config 3 on one GPU: a LAFAN1-sized set (77 clips of 2000-9000 frames, bvh_to_g1.json)
+        lc = long_clip_set(cm, synth, dev)
+        t_seq, (q_seq, it_seq, _) = timed(lambda: lc["eng"].ik_solve(lc["pos"], lc["quat"], lc["sc"], make_items(lc["offs"])), reps=2)
+        t_chk, (q_chk, it_chk, info) = timed(lambda: lc["eng"].ik_solve_chunked(lc["pos"], lc["quat"], lc["sc"], lc["offs"], chunk=64, burn_in=32), reps=3)
+        result["long_clips"] = {"clips": len(lc["offs"]) - 1, "frames": int(lc["offs"][-1]), "config": "bvh_to_g1 (LAFAN1-sized: 77 clips of 2000-9000 frames, half noisy)",
+                                "sequential_frames_per_s": int(lc["offs"][-1]) / t_seq, "verified_chunked_frames_per_s": int(lc["offs"][-1]) / t_chk,
+                                "chunk": 64, "burn_in": 32, "resolved_frames": info["resolved_frames"],
+                                "max_abs_diff_vs_sequential": float((q_chk - q_seq).abs().max().item()),
+                                "frames_with_different_solve_count": int((it_chk != it_seq).sum().item())}
+        del lc
+        # live single-sequence mode (gmr_session_*): host frame in -> host qpos out, one launch per frame
+        ses = eng.session(sc, int(pos.shape[1]), dtype=np.float32)
+        hp, hq = pos[:256].cpu().numpy(), quat[:256].cpu().numpy()
+        lat = []
+        for i in range(256):
             t1 = time.perf_counter()
-            orc.ik_solve(cp[: one * T], cq[: one * T], sc, make_items(offs[: one + 1]), n_threads=1)
-            t_one = time.perf_counter() - t1
-            t1 = time.perf_counter()
-            q_ref, it_ref, _ = orc.ik_solve(cp, cq, sc, citems, n_threads=cores)
-            t_all = time.perf_counter() - t1
-            q_gpu = out[: nc * T].cpu().numpy()
+            ses.step(hp[i], hq[i])
+            lat.append(time.perf_counter() - t1)
+        ses.close()
+        lat = np.array(lat[16:]) * 1e6
+        result["live_session"] = {"frames": int(lat.size), "median_latency_us": float(np.median(lat)), "p99_latency_us": float(np.quantile(lat, 0.99)),
+                                  "frames_per_s": float(1e6 / lat.mean()), "includes": "host staging + launch + kernel + sync, one wavefront"}
+        # the same path fed from / returned to HOST arrays (what retarget_batch does for numpy callers): PCIe inclusive,
+        # pinned double-buffered staging, copies overlapped with the kernel (Engine.ik_solve_host); never part of `value`
+        nh = min(S, 4096) * T
+        hp_all, hq_all = pos[:nh].cpu().numpy(), quat[:nh].cpu().numpy()
+        h_offs = offs[: nh // T + 1]
+        t_host, (q_host, _) = timed(lambda: eng.ik_solve_host(hp_all, hq_all, sc, h_offs, want_iters=False), reps=3)
+        same = bool(np.array_equal(q_host, out[:nh].cpu().numpy()))
+
+        def serial():
+            q_h, _, _ = eng.ik_solve(torch.from_numpy(hp_all[: nh // 4]).to(dev), torch.from_numpy(hq_all[: nh // 4]).to(dev), sc, make_items(h_offs[: nh // 4 // T + 1]), want_iters=False)
+            return q_h.cpu().numpy()
+        t_ser, _ = timed(serial, reps=2)
+        result["host_fed"] = {"frames": nh, "frames_per_s": nh / t_host, "bitwise_equal_to_resident": same,
+                              "serial_pageable_frames_per_s": (nh // 4) / t_ser,
+                              "includes": "pageable host key-points -> pinned staging -> H2D (392 B/frame) + kernel + D2H of qpos (288 B/frame) into a pinned "
+                                          "host result, two streams; serial_pageable = round 1's copy-in / solve / copy-out without overlap"}
+        del hp_all, hq_all, q_host
+    if rank == 0 and world == 1 and not args.no_cpu and not args.hot_only:
+        from oracle.oracle import Oracle  # checker / comparator only
+        orc = Oracle(cm.blob)
+        cores = host_cores()
+        nc = min(args.cpu_clips if args.cpu_clips > 0 else min(512, max(32, 4 * cores)), S)
+        cp, cq = pos[: nc * T].cpu().numpy(), quat[: nc * T].cpu().numpy()
+        citems = make_items(offs[: nc + 1])
+        one = 4
+        t1 = time.perf_counter()
+        orc.ik_solve(cp[: one * T], cq[: one * T], sc, make_items(offs[: one + 1]), n_threads=1)
+        t_one = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        q_ref, it_ref, _ = orc.ik_solve(cp, cq, sc, citems, n_threads=cores)
+        t_all = time.perf_counter() - t1
+        result["cpu_baseline"] = {
+            "value": nc * T / t_all, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{nc} of the headline workload's clips x {T} frames, clip-parallel OpenMP on {cores} threads, float64 C oracle",
+            "single_core_value": one * T / t_one, "single_core_sample": f"{one} clip(s) x {T} frames",
+            "reference_published": "35-70 frames/s single Python process (README.md:617-620, other hardware, config unstated)",
+        }
+
+        def parity(q_gpu, it_gpu, q_ref, it_ref):
             d = np.abs(q_gpu - q_ref)
-            it_gpu = (iters[: nc * T] & 0x3FFFFFFF).cpu().numpy()
-            result["cpu_baseline"] = {
-                "value": nc * T / t_all, "unit": "frames/s", "cores": cores, "kind": "port",
-                "sample": f"{nc} of the benchmark's clips x {T} frames, clip-parallel OpenMP on {cores} threads, float64 C oracle",
-                "single_core_value": one * T / t_one, "single_core_sample": f"{one} clip(s) x {T} frames",
-                "reference_published": "35-70 frames/s single Python process (README.md:617-620, other hardware, config unstated)",
-            }
             # root rotation error as the geodesic angle between the two unit quaternions
             dots = np.abs(np.sum(q_gpu[:, 3:7] * q_ref[:, 3:7], axis=1)) / (
                 np.linalg.norm(q_gpu[:, 3:7], axis=1) * np.linalg.norm(q_ref[:, 3:7], axis=1))
             geo = 2.0 * np.arccos(np.clip(dots, 0.0, 1.0))
-            result["parity"] = {
-                "max_abs_qpos_err_vs_cpu": float(d.max()), "max_abs_hinge_err_rad": float(d[:, 7:].max()),
-                "p999_abs_hinge_err_rad": float(np.quantile(d[:, 7:].max(axis=1), 0.999)),
-                "max_root_pos_err_m": float(np.linalg.norm(q_gpu[:, :3] - q_ref[:, :3], axis=1).max()),
-                "max_root_geodesic_err_rad": float(geo.max()),
-                "frames_compared": int(nc * T), "frames_with_different_solve_count": int((it_gpu != it_ref).sum()),
-                "tolerance_target_rad": 1e-3,
-            }
+            return {"max_abs_qpos_err_vs_cpu": float(d.max()), "max_abs_hinge_err_rad": float(d[:, 7:].max()),
+                    "p999_abs_hinge_err_rad": float(np.quantile(d[:, 7:].max(axis=1), 0.999)),
+                    "max_root_pos_err_m": float(np.linalg.norm(q_gpu[:, :3] - q_ref[:, :3], axis=1).max()),
+                    "max_root_geodesic_err_rad": float(geo.max()), "frames_compared": int(q_ref.shape[0]),
+                    "frames_with_different_solve_count": int((it_gpu != it_ref).sum())}
+        result["parity"] = {**parity(out[: nc * T].cpu().numpy(), (iters[: nc * T] & 0x3FFFFFFF).cpu().numpy(), q_ref, it_ref), "tolerance_target_rad": 1e-3}
+        if un is not None:
+            # the un-shaped clips too: the first nc clips in memory order (lengths differ)
+            e = int(uoffs[nc])
+            t1 = time.perf_counter()
+            uq_ref, uit_ref, _ = orc.ik_solve(upos[:e].cpu().numpy(), uquat[:e].cpu().numpy(), usc, make_items(uoffs[: nc + 1]), n_threads=cores)
+            t_u = time.perf_counter() - t1
+            result["parity"]["unshaped"] = parity(uout[:e].cpu().numpy(), (uiters[:e] & 0x3FFFFFFF).cpu().numpy(), uq_ref, uit_ref)
+            result["cpu_baseline"]["unshaped_value"] = e / t_u
+    if rank == 0:
         print(json.dumps(result), flush=True)
     barrier()
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def _dataset_device(gmr, dataset, pos, quat, names, offs):
+    """IK + the two FK passes + root adjustments with everything left on the device (dataset.motions_from_qpos minus its D2H)."""
+    import numpy as np
+    import torch
+    qpos = gmr.retarget_batch(pos, quat, names, seq_offsets=offs)
+    eng = gmr._engine
+    N = int(qpos.shape[0])
+    root_pos = qpos[:, 0:3].clone()
+    root_rot = qpos[:, [4, 5, 6, 3]].contiguous()
+    dof32 = qpos[:, 7:].to(torch.float32)
+    zeros = torch.zeros((N, 3), dtype=torch.float32, device=qpos.device)
+    ident = torch.zeros((N, 4), dtype=torch.float32, device=qpos.device)
+    ident[:, 3] = 1.0
+    local_body_pos, _ = eng.fk(zeros, ident, dof32, want_rot=False)
+    lowest = eng.fk_min_height(root_pos.to(torch.float32), root_rot.to(torch.float32), dof32, offs).to(torch.float64)
+    lens = torch.from_numpy(np.diff(offs)).to(qpos.device)
+    root_pos[:, 2] -= torch.repeat_interleave(lowest, lens)
+    root_pos[:, :2] -= torch.repeat_interleave(root_pos[torch.from_numpy(offs[:-1]).to(qpos.device), :2], lens, dim=0)
+    return root_pos, root_rot, local_body_pos
+
+
+def long_clip_set(cm_unused, synth, dev, n_clips=77, seed=3):
+    """BASELINE config 3's shape: a LAFAN1-sized set -- 77 clips of 2000..9000 frames, bvh_to_g1.json, half of the base clips
+    noisy / over-reaching (tools/config3_bench.py)."""
+    import numpy as np
+    import torch
+    from gmr_amd import params
+    from gmr_amd.engine import Engine
+    from gmr_amd.ik_config import load_ik_config
+    from gmr_amd.mjcf import load_robot
+    from gmr_amd.model import compile_model
+    cmb = compile_model(load_robot(params.ROBOT_XML_DICT[ROBOT], name=ROBOT), load_ik_config(params.IK_CONFIG_DICT["bvh"][ROBOT]))
+    eng = Engine(cmb, dev.index)
+    rng = np.random.default_rng(seed)
+    lengths = rng.integers(2000, 9001, size=n_clips)
+    hard = rng.integers(2, size=n_clips).astype(bool)
+    pos, quat, names, offs = synth.synth_clips_torch(cmb, lengths, seed=33, device=dev, hard=hard, yaw0=np.pi)
+    return {"eng": eng, "pos": pos, "quat": quat, "sc": cmb.slot_columns(names), "offs": offs}
 
 
 if __name__ == "__main__":

@@ -127,6 +127,91 @@ class Engine:
         self.last_stats = stats
         return out, iters, qfin
 
+    def ik_solve_host(self, pos: np.ndarray, quat: np.ndarray, slot_col: np.ndarray, seq_offsets, params: Optional[IKParams] = None,
+                      height_scales=None, batch_frames: int = 1 << 20, want_iters: bool = True, check: bool = True):
+        """Whole clips from HOST arrays to a HOST result, pipelined: what the dataset scripts hand over
+        (scripts/smplx_to_robot_dataset.py:84-89 builds host key-points per file) without a serial copy-in / solve / copy-out.
+
+        Clips are grouped into batches of about ``batch_frames`` frames.  Two HIP streams, each with its own pinned staging
+        buffer and device buffers: while stream A's batch is in flight (H2D of 392 B/frame, kernel, D2H of 288 B/frame straight
+        into the pinned result), the host fills stream B's staging buffer with the next batch -- only the columns the config
+        consumes are staged (14 of 55 SMPL-X joints).  Results are bitwise those of ``ik_solve`` on resident tensors (same
+        kernel, same per-clip work items).  With ``check`` every batch is inspected on the device (non-finite qpos ->
+        FloatingPointError, a capped QP -> RuntimeError).  Returns (qpos [N, nq] float64, iters [N] int32 or None) as numpy
+        arrays backed by pinned memory.
+        """
+        from .schedule import make_items
+        if pos.dtype != quat.dtype or pos.dtype not in (np.float32, np.float64):
+            raise EngineError("pos/quat must both be float32 or both float64")
+        if pos.ndim != 3 or quat.ndim != 3 or pos.shape[2] != 3 or quat.shape[2] != 4 or pos.shape[:2] != quat.shape[:2]:
+            raise EngineError(f"bad input shapes {pos.shape} / {quat.shape}")
+        offs = np.asarray(seq_offsets, dtype=np.int64)
+        N, ns = int(pos.shape[0]), self.info.nslot
+        if offs[0] != 0 or offs[-1] != N:
+            raise EngineError("seq_offsets must span [0, N]")
+        slot_col = np.ascontiguousarray(slot_col, dtype=np.int32)
+        cols_t = torch.from_numpy(slot_col.astype(np.int64))
+        ident = np.arange(ns, dtype=np.int32)
+        tdt = torch.float32 if pos.dtype == np.float32 else torch.float64
+        hs = None if height_scales is None else np.asarray(height_scales, dtype=np.float64)
+        # batches of whole clips
+        bounds = [0]
+        for s in range(len(offs) - 1):
+            if offs[s + 1] - offs[bounds[-1]] >= batch_frames and s + 1 < len(offs) - 1:
+                bounds.append(s + 1)
+        bounds.append(len(offs) - 1)
+        cap = max(int(offs[bounds[k + 1]] - offs[bounds[k]]) for k in range(len(bounds) - 1)) if N else 0
+        out = torch.empty((N, self.nq), dtype=torch.float64, pin_memory=True)
+        iters = torch.empty(N, dtype=torch.int32, pin_memory=True) if want_iters else None
+        if N == 0:
+            return out.numpy(), (iters.numpy() if want_iters else None)
+        tpos, tquat = torch.from_numpy(pos), torch.from_numpy(quat)
+        nbuf = min(2, len(bounds) - 1)
+        st = [torch.cuda.Stream(self.device) for _ in range(nbuf)]
+        hp = [torch.empty((cap, ns, 3), dtype=tdt, pin_memory=True) for _ in range(nbuf)]
+        hq = [torch.empty((cap, ns, 4), dtype=tdt, pin_memory=True) for _ in range(nbuf)]
+        dp = [torch.empty((cap, ns, 3), dtype=tdt, device=self.device) for _ in range(nbuf)]
+        dq = [torch.empty((cap, ns, 4), dtype=tdt, device=self.device) for _ in range(nbuf)]
+        do = [torch.empty((cap, self.nq), dtype=torch.float64, device=self.device) for _ in range(nbuf)]
+        di = [torch.empty(cap, dtype=torch.int32, device=self.device) for _ in range(nbuf)] if want_iters else None
+        staged = [None] * nbuf  # event: the H2D copies out of staging buffer b have completed
+        want_i = want_iters or check
+        if check and di is None:
+            di = [torch.empty(cap, dtype=torch.int32, device=self.device) for _ in range(nbuf)]
+        flags = torch.zeros((nbuf, 2), dtype=torch.int32, device=self.device)
+        for k in range(len(bounds) - 1):
+            b = k % nbuf
+            c0, c1 = bounds[k], bounds[k + 1]
+            f0, f1 = int(offs[c0]), int(offs[c1])
+            n = f1 - f0
+            if staged[b] is not None:
+                staged[b].synchronize()
+            torch.index_select(tpos[f0:f1], 1, cols_t, out=hp[b][:n])
+            torch.index_select(tquat[f0:f1], 1, cols_t, out=hq[b][:n])
+            items = make_items(offs[c0:c1 + 1] - f0, height_scales=None if hs is None else hs[c0:c1])
+            with torch.cuda.stream(st[b]):
+                dp[b][:n].copy_(hp[b][:n], non_blocking=True)
+                dq[b][:n].copy_(hq[b][:n], non_blocking=True)
+                staged[b] = torch.cuda.Event()
+                staged[b].record()
+                self.ik_solve(dp[b][:n], dq[b][:n], ident, items, params=params, out=do[b][:n],
+                              iters=di[b][:n] if want_i else None, want_iters=want_i)
+                if check:
+                    flags[b, 0] |= (~torch.isfinite(do[b][:n])).any().to(torch.int32)
+                    flags[b, 1] |= (di[b][:n] >> 30).ne(0).any().to(torch.int32)
+                out[f0:f1].copy_(do[b][:n], non_blocking=True)
+                if want_iters:
+                    iters[f0:f1].copy_(di[b][:n], non_blocking=True)
+        for s_ in st:
+            s_.synchronize()
+        if check:
+            bad = flags.sum(0).cpu().numpy()
+            if bad[0]:
+                raise FloatingPointError("non-finite qpos")
+            if bad[1]:
+                raise RuntimeError("a box QP hit its iteration cap (the reference would assert on a failed QP)")
+        return out.numpy(), (iters.numpy() if want_iters else None)
+
     def ik_solve_chunked(self, pos: torch.Tensor, quat: torch.Tensor, slot_col: np.ndarray, seq_offsets, chunk: int, burn_in: int,
                          params: Optional[IKParams] = None, eps: float = 1e-7, height_scales=None,
                          chunk_init: int = _native.INIT_ROOT_TARGET):

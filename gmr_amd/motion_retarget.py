@@ -100,6 +100,8 @@ class _FrameTask:
 class GeneralMotionRetargeting:
     """General Motion Retargeting (GMR) on gfx950."""
 
+    HOST_PIPELINE_MIN_FRAMES = 1 << 18  # numpy batches at least this long go through the overlapped host pipeline
+
     def __init__(
         self,
         src_human: str,
@@ -266,6 +268,19 @@ class GeneralMotionRetargeting:
         """
         is_np = isinstance(pos, np.ndarray)
         cols = self._columns(list(body_names))  # KeyError where the reference raises
+        if is_np and isinstance(quat, np.ndarray) and chunk == 0 and pos.ndim == 3 and pos.shape[0] >= self.HOST_PIPELINE_MIN_FRAMES:
+            # big host batches: pinned double-buffered pipeline, copies overlapped with the kernel (Engine.ik_solve_host)
+            N = int(pos.shape[0])
+            offs = np.asarray([0, N] if seq_offsets is None else seq_offsets, dtype=np.int64)
+            hs = None
+            if human_heights is not None:
+                hh = np.asarray(human_heights, dtype=np.float64)
+                if hh.shape != (len(offs) - 1,):
+                    raise ValueError("human_heights must hold one height per clip")
+                hs = hh / self._cm.config.human_height_assumption / self._cm.ratio
+            out, iters = self._engine.ik_solve_host(pos, quat, cols, offs, params=self._params(offset_to_ground), height_scales=hs,
+                                                    want_iters=return_iters, check=check)
+            return (out, iters) if return_iters else out
         if is_np and isinstance(quat, np.ndarray) and pos.ndim == 3 and pos.shape[1] > len(cols):
             # host arrays with more bodies than the config consumes (55 SMPL-X joints, 14 used): gather the used columns on the
             # host first -- a quarter of the bytes cross PCIe

@@ -175,3 +175,139 @@ def synth_clips(cm: CompiledModel, n_clips: int, T: int, seed: int = 0, hard: bo
     quat = np.concatenate(Q).astype(dtype)
     offs = np.arange(n_clips + 1, dtype=np.int64) * T
     return pos, quat, names, offs, np.concatenate(G)
+
+
+# ------------------------------------------------------------------ the same generator on a torch device
+# bench.py's "unshaped" workload (every clip distinct, any initial heading, variable lengths) is 2.5e7 frames: minutes of
+# numpy on the host, seconds as torch tensor ops on the GPU.  Same construction as above (trajectory -> FK -> inverse target
+# preparation), drawn from a torch.Generator; workload generation only, not a compute path of the engine.
+def _t_qmul(a, b):
+    import torch
+    aw, ax, ay, az = a.unbind(-1)
+    bw, bx, by, bz = b.unbind(-1)
+    return torch.stack([aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                        aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw], dim=-1)
+
+
+def _t_qrot(q, v):
+    import torch
+    w, u = q[..., :1], q[..., 1:]
+    t = 2.0 * torch.cross(u, v.expand_as(u), dim=-1)
+    return v + w * t + torch.cross(u, t, dim=-1)
+
+
+def _t_qexp(rv):
+    import torch
+    ang = rv.norm(dim=-1, keepdim=True)
+    half = 0.5 * ang
+    k = torch.where(ang > 1e-12, torch.sin(half) / ang.clamp_min(1e-300), torch.full_like(ang, 0.5))
+    return torch.cat([torch.cos(half), k * rv], dim=-1)
+
+
+def _t_lowpass(x, k):
+    """Centred moving average of width k along dim 1 of [S, T, C] (numpy's convolve(mode="same") with a box)."""
+    import torch
+    S, T, C = x.shape
+    k = max(1, min(k, T))
+    w = torch.ones((C, 1, k), dtype=x.dtype, device=x.device) / k
+    lo = (k - 1) // 2 + ((k - 1) % 2)  # np.convolve 'same' centring for even k
+    y = torch.nn.functional.pad(x.permute(0, 2, 1), (lo, k - 1 - lo))
+    return torch.nn.functional.conv1d(y, w, groups=C).permute(0, 2, 1)
+
+
+def synth_clips_torch(cm: CompiledModel, lengths, seed: int, device, hard=False, yaw0: float = np.pi, amp: float = 0.35,
+                      fps: float = 30.0, dtype=None, clips_per_pass: int = 256):
+    """Clips of the given lengths, all distinct, generated on ``device``: (pos [N,B,3], quat [N,B,4], names, seq_offsets).
+
+    ``hard``: bool, or a bool per clip (2 cm / 5 deg noise + 1.1x arm reach, as in the numpy generator).  ``yaw0 = pi``: any
+    initial heading, like real capture data (the numpy generator's default of 1 rad keeps a clip's first frames out of the
+    reference algorithm's slow far-heading start-up)."""
+    import torch
+    dtype = dtype or torch.float32
+    robot = cm.robot
+    lengths = np.asarray(lengths, dtype=np.int64)
+    S = len(lengths)
+    hard = np.broadcast_to(np.asarray(hard, dtype=bool), (S,))
+    offs = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    N, ns = int(offs[-1]), cm.nslot
+    pos = torch.empty((N, ns, 3), dtype=dtype, device=device)
+    quat = torch.empty((N, ns, 4), dtype=dtype, device=device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed))
+    f64 = torch.float64
+    U = lambda shape, lo, hi: lo + (hi - lo) * torch.rand(shape, generator=gen, dtype=f64, device=device)  # noqa: E731
+    Nrm = lambda shape: torch.randn(shape, generator=gen, dtype=f64, device=device)  # noqa: E731
+    T_ = lambda a: torch.as_tensor(np.asarray(a), dtype=f64, device=device)  # noqa: E731
+    slot_body = np.full(ns, -1, dtype=np.int64)
+    for tb, ts in zip(cm.task_body[0], cm.task_slot[0]):
+        slot_body[ts] = tb
+    scale, poff, roff = T_(cm.slot_scale), T_(cm.slot_pos_off), T_(cm.slot_rot_off)
+    roff_c = roff * T_([1.0, -1.0, -1.0, -1.0])
+    stretch = np.array([any(k in n.lower() for k in ("elbow", "wrist", "forearm", "hand")) for n in cm.slot_names])
+    rs = cm.root_slot
+    order = np.argsort(-lengths, kind="stable")
+    for p0 in range(0, S, clips_per_pass):
+        ids = order[p0:p0 + clips_per_pass]
+        s, Tm = len(ids), int(lengths[ids].max())
+        t = torch.arange(Tm, dtype=f64, device=device) / fps
+        qpos = torch.zeros((s, Tm, robot.nq), dtype=f64, device=device)
+        for b in robot.hinge_bodies():
+            lo, hi = robot.jnt_range[b] if robot.jnt_limited[b] else (-1.0, 1.0)
+            a, f, ph = U((s, 4, 1), 0.2, 1.0), U((s, 4, 1), 0.1, 1.5), U((s, 4, 1), 0.0, 2 * np.pi)
+            sig = (a * torch.sin(2 * np.pi * f * t + ph)).sum(1) / a.abs().sum(1)
+            qpos[:, :, robot.qpos_adr[b]] = 0.5 * (lo + hi) + amp * (hi - lo) * sig
+        k = max(3, int(fps))
+        vel = _t_lowpass(Nrm((s, Tm, 2)), k)
+        vel = vel / vel.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1e-9) * 1.5 * U((s, 1, 1), 0.2, 1.0)
+        qpos[:, :, 0:2] = torch.cumsum(vel, dim=1) / fps
+        qpos[:, :, 2] = robot.body_pos[0, 2] + 0.05 * torch.sin(2 * np.pi * U((s, 1), 0.2, 1.0) * t + U((s, 1), 0.0, 6.28))
+        yr = _t_lowpass(Nrm((s, Tm, 1)), k)[:, :, 0]
+        yr = yr / yr.abs().amax(dim=1, keepdim=True).clamp_min(1e-9) * U((s, 1), 0.2, 1.0)
+        yaw = U((s, 1), -yaw0, yaw0) + torch.cumsum(yr, dim=1) / fps
+        roll = 0.2 * torch.sin(2 * np.pi * U((s, 1), 0.1, 0.8) * t + U((s, 1), 0.0, 6.28)) * U((s, 1), 0.0, 1.0)
+        pitch = 0.2 * torch.sin(2 * np.pi * U((s, 1), 0.1, 0.8) * t + U((s, 1), 0.0, 6.28)) * U((s, 1), 0.0, 1.0)
+        z = torch.zeros_like(yaw)
+        qpos[:, :, 3:7] = _t_qmul(_t_qmul(_t_qexp(torch.stack([z, z, yaw], -1)), _t_qexp(torch.stack([z, pitch, z], -1))),
+                                  _t_qexp(torch.stack([roll, z, z], -1)))
+        # FK (MuJoCo convention) for the bodies the tasks need
+        q2 = qpos.reshape(s * Tm, robot.nq)
+        need = np.zeros(robot.nbody, dtype=bool)
+        for b in slot_body:
+            while b >= 0 and not need[b]:
+                need[b] = True
+                b = robot.parent[b]
+        xpos, xquat = {0: q2[:, 0:3]}, {0: q2[:, 3:7] / q2[:, 3:7].norm(dim=-1, keepdim=True)}
+        for b in range(1, robot.nbody):
+            if not need[b]:
+                continue
+            p = int(robot.parent[b])
+            xpos[b] = xpos[p] + _t_qrot(xquat[p], T_(robot.body_pos[b]))
+            q = _t_qmul(xquat[p], T_(robot.body_quat[b]).expand(s * Tm, 4))
+            if robot.jnt_type[b] == JNT_HINGE:
+                th = q2[:, robot.qpos_adr[b]]
+                q = _t_qmul(q, torch.cat([torch.cos(0.5 * th)[:, None], torch.sin(0.5 * th)[:, None] * T_(robot.jnt_axis[b])], -1))
+            xquat[b] = q / q.norm(dim=-1, keepdim=True)
+        tpos = torch.stack([xpos[int(b)] for b in slot_body], 1)     # [s*Tm, ns, 3]
+        tquat = torch.stack([xquat[int(b)] for b in slot_body], 1)
+        del xpos, xquat
+        hm = torch.as_tensor(hard[ids], device=device).repeat_interleave(Tm)
+        if bool(hard[ids].any()):
+            tpos = tpos + hm[:, None, None] * 0.02 * Nrm(tpos.shape)
+            noise = _t_qexp(np.deg2rad(5.0) * Nrm(tpos.shape))
+            tquat = torch.where(hm[:, None, None], _t_qmul(tquat, noise), tquat)
+            root_t = tpos[:, rs:rs + 1]
+            far = root_t + 1.1 * (tpos - root_t)
+            sel = hm[:, None, None] & torch.as_tensor(stretch, device=device)[None, :, None]
+            tpos = torch.where(sel, far, tpos)
+        hquat = _t_qmul(tquat, roff_c.expand_as(tquat))
+        p1 = tpos - _t_qrot(tquat, poff.expand_as(tpos))
+        root_h = p1[:, rs] / scale[rs]
+        hpos = (p1 - p1[:, rs:rs + 1]) / scale[None, :, None] + root_h[:, None, :]
+        hpos[:, rs] = root_h
+        hpos, hquat = hpos.reshape(s, Tm, ns, 3), hquat.reshape(s, Tm, ns, 4)
+        for j, c in enumerate(ids):
+            L = int(lengths[c])
+            pos[offs[c]:offs[c] + L] = hpos[j, :L].to(dtype)
+            quat[offs[c]:offs[c] + L] = hquat[j, :L].to(dtype)
+        del hpos, hquat, tpos, tquat, qpos, q2
+    return pos, quat, list(cm.slot_names), offs

@@ -507,21 +507,29 @@ def test_error1_equals_error2_for_same_map_tables():
 
 
 def test_bench_two_rank_path_rehearsal():
-    """bench.py's N > 1 path (rank discovery, model broadcast, barrier + max-over-ranks timing, rank-0 JSON) with two ranks
-    sharing this box's one GPU and gloo collectives -- everything the 8-GPU run does except RCCL itself."""
+    """bench.py's N > 1 path, started the way a driver without a launcher would (`python bench.py --gpus 2`: the script spawns its
+    own ranks): rank discovery, model broadcast, barrier + max-over-ranks timing, the timed exchange steps (all-gather of qpos,
+    strong-scaling split, long clips with chunks sharded over the ranks), rank-0 JSON -- two ranks sharing this box's one GPU
+    with gloo collectives, i.e. everything the 8-GPU run does except RCCL itself."""
     import subprocess
     import sys
-    env = dict(os.environ, GMR_BENCH_BACKEND="gloo", GMR_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(GMR_BENCH_BACKEND="gloo", GMR_BENCH_SHARE_GPU="1")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--clips", "64", "--frames", "60"]
-    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr[-2000:]
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--clips", "64", "--frames", "60"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]  # rank 0 only
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["frames_per_step"] == 2 * 64 * 60
     assert d["value"] > 0 and abs(d["value"] - d["config"]["frames_per_step"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["value_unshaped"] > 0 and d["roofline"]["bound"] == "fp64-vector" and d["hbm"]["non_binding"]
+    c = d["collectives"]
+    assert c["rccl_ranks"] == 2 and c["allgather_complete"] and c["allgather_qpos_ms"] > 0 and c["allgather_bytes_per_rank"] == 64 * 60 * 36 * 8
+    assert d["strong"]["clips_total"] == 64 and d["strong"]["value"] > 0
+    lc = d["long_clips_sharded"]
+    assert lc["ranks"] == 2 and lc["clips"] == 77 and lc["frames_per_s"] > 0 and lc["resolved_frames"] < 0.05 * lc["frames"]
 
 
 def test_caller_access_pattern_of_fbx_to_robot():
