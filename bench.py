@@ -332,9 +332,12 @@ def main():
         root_pos32 = out[:, 0:3].to(torch.float32).contiguous()
         root_rot32 = out[:, [4, 5, 6, 3]].to(torch.float32).contiguous()
         dof32 = out[:, 7:].to(torch.float32).contiguous()
-        fk_el, fk_ms, _ = timed_steps(lambda: eng.fk(root_pos32, root_rot32, dof32, want_rot=False), 3, 1)
+        bp_out = torch.empty((nf, eng.nbody, 3), dtype=torch.float32, device=dev)
+        fk_el, fk_ms, _ = timed_steps(lambda: eng.fk(root_pos32, root_rot32, dof32, want_rot=False, out_pos=bp_out), 3, 1)
         fk_bytes = (7 + eng.nq - 7) * 4 + eng.nbody * 12
-        fk_el2, fk_ms2, _ = timed_steps(lambda: eng.fk(root_pos32[: nf // 2], root_rot32[: nf // 2], dof32[: nf // 2], want_rot=True), 3, 1)
+        br_out = torch.empty((nf // 2, eng.nbody, 4), dtype=torch.float32, device=dev)
+        fk_el2, fk_ms2, _ = timed_steps(lambda: eng.fk(root_pos32[: nf // 2], root_rot32[: nf // 2], dof32[: nf // 2], want_rot=True,
+                                                       out_pos=bp_out[: nf // 2], out_rot=br_out), 3, 1)
         fk_bytes2 = fk_bytes + eng.nbody * 16
         result["fk"] = {
             "kernel": "gmr::fk_kernel<0>", "frames": nf, "kernel_ms": fk_ms, "frames_per_s": nf / (fk_ms * 1e-3),
@@ -343,7 +346,7 @@ def main():
             "with_rotations": {"frames": nf // 2, "kernel_ms": fk_ms2, "bytes_per_frame": fk_bytes2,
                                "frac": fk_bytes2 * (nf // 2) / (fk_ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
-        del root_pos32, root_rot32, dof32
+        del root_pos32, root_rot32, dof32, bp_out, br_out
     if rank == 0 and world == 1 and not args.hot_only:
         from gmr_amd import dataset
 

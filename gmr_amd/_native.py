@@ -25,7 +25,7 @@ assert WORK_ITEM_DTYPE.itemsize == 40
 INIT_QPOS0, INIT_ROOT_TARGET = -1, -2
 
 EXPORTS = ["gmr_abi_version", "gmr_model_create", "gmr_model_destroy", "gmr_last_error", "gmr_model_info_get",
-           "gmr_ik_solve", "gmr_fk", "gmr_fk_min_height", "gmr_bvh_fk", "gmr_bvh_parse_motion", "gmr_evaluate", "gmr_smplx_keypoints",
+           "gmr_ik_solve", "gmr_fk", "gmr_fk_min_height", "gmr_bvh_fk", "gmr_bvh_parse_header", "gmr_bvh_parse_motion", "gmr_evaluate", "gmr_smplx_keypoints",
            "gmr_session_create", "gmr_session_destroy", "gmr_session_reset", "gmr_session_step", "gmr_session_state"]
 
 
@@ -91,6 +91,8 @@ def load():
     L.gmr_fk.argtypes = [vp, vp, vp, vp, C.c_int64, vp, vp, vp]
     L.gmr_fk_min_height.restype = C.c_int
     L.gmr_fk_min_height.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp]
+    L.gmr_bvh_parse_header.restype = C.c_int
+    L.gmr_bvh_parse_header.argtypes = [C.c_char_p, C.c_size_t, C.c_int, vp, C.c_size_t, vp, vp, vp, vp, vp, vp, vp]
     L.gmr_evaluate.restype = C.c_int
     L.gmr_evaluate.argtypes = [vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.gmr_smplx_keypoints.restype = C.c_int

@@ -1,11 +1,12 @@
 """BVH input adapter on the fast path.
 
 Mirror of ``load_lafan1_file`` (reference general_motion_retargeting/utils/lafan1.py:8-71) with the reference's
-own file semantics (``read_bvh``, utils/lafan_vendor/extract.py:43-166): hierarchy parsed line by line, the Euler
-order taken from the first CHANNELS line, the channel count from the last one, root translation from the first three
-motion columns, non-root local positions = joint offsets.  The hierarchy (a few dozen lines) is parsed in Python; the
-MOTION block -- the bulk of the file, and the regex + float() loop that dominates loading in the reference -- goes through
-the library's native parser (``gmr_bvh_parse_motion``, correctly rounded like ``float()``); Euler -> quaternion, the quaternion FK, the Y-up -> Z-up turn, cm -> m and the ``LeftFootMod`` /
+own file semantics (``read_bvh``, utils/lafan_vendor/extract.py:43-166): the Euler order taken from the first joint's
+channels, the channel count from the last joint's, root translation from the first three motion columns, non-root local
+positions = joint offsets.  Both text stages are native host code of the library: the HIERARCHY section goes through a
+token grammar (``gmr_bvh_parse_header``, gmr_amd/csrc/bvh_text.h), the MOTION block -- the bulk of the file, and the
+regex + float() loop that dominates loading in the reference -- through ``gmr_bvh_parse_motion`` (correctly rounded like
+``float()``); Euler -> quaternion, the quaternion FK, the Y-up -> Z-up turn, cm -> m and the ``LeftFootMod`` /
 ``RightFootMod`` synthesis run in one HIP kernel (``gmr_bvh_fk``) and the result stays on the GPU as the
 ``[T, B, 3]`` / ``[T, B, 4]`` tensors ``retarget_batch`` consumes -- no per-frame dicts unless asked for.
 
@@ -15,7 +16,6 @@ only flips signs; every consumer is sign-insensitive); 9-channel files are rejec
 from __future__ import annotations
 
 import ctypes as C
-import re
 from typing import Dict, List, Tuple
 
 import numpy as np
@@ -52,72 +52,45 @@ def _parse_motion(block: bytes, fnum: int, max_cols: int, filename: str) -> np.n
     return out[:n].reshape(fnum, n_cols.value)
 
 
+def _parse_header(raw: bytes, filename: str):
+    """HIERARCHY section + MOTION header through the library's tokenizer (``gmr_bvh_parse_header``, grammar in
+    gmr_amd/csrc/bvh_text.h).  Returns (names, parents, offsets, channels per joint, euler order, n_frames, frame time, motion offset)."""
+    lib = _native.load()
+    vp = C.c_void_p
+    max_j = 64
+    while True:
+        names_buf = C.create_string_buffer(64 * max_j)
+        parents = np.empty(max_j, dtype=np.int32)
+        offsets = np.empty((max_j, 3), dtype=np.float64)
+        channels = np.empty(max_j, dtype=np.int32)
+        order = np.empty(3, dtype=np.int32)
+        fnum, ftime, moff = C.c_int64(0), C.c_double(0.0), C.c_size_t(0)
+        n = lib.gmr_bvh_parse_header(raw, len(raw), max_j, names_buf, len(names_buf), parents.ctypes.data_as(vp), offsets.ctypes.data_as(vp),
+                                     channels.ctypes.data_as(vp), order.ctypes.data_as(vp), C.byref(fnum), C.byref(ftime), C.byref(moff))
+        if n == -2 and max_j < (1 << 16):
+            max_j *= 4
+            continue
+        if n <= 0:
+            raise ValueError(f"{filename}: not a BVH file this loader understands")
+        names = names_buf.raw.split(b"\0")[:n]
+        return ([x.decode("ascii") for x in names], parents[:n].copy(), offsets[:n].copy(), channels[:n].copy(),
+                tuple(int(x) for x in order), int(fnum.value), float(ftime.value), int(moff.value))
+
+
 def read_bvh(filename: str) -> BvhAnim:
     with open(filename, "rb") as f:
         raw = f.read()
-    cut = raw.find(b"Frame Time:")
-    if cut < 0:
-        raise ValueError(f"{filename}: not a BVH file this loader understands")
-    eol = raw.find(b"\n", cut)
-    eol = len(raw) if eol < 0 else eol + 1
-    lines = raw[:eol].decode("utf-8", errors="replace").split("\n")  # the header, up to and including the Frame Time line
-    motion_block = raw[eol:]
-    names: List[str] = []
-    offsets: List[List[float]] = []
-    parents: List[int] = []
-    active, end_site, order, channels, fnum, frametime = -1, False, None, None, None, None
-    i = 0
-    while i < len(lines):
-        line = lines[i]
-        i += 1
-        if "HIERARCHY" in line or "MOTION" in line:
-            continue
-        m = re.match(r"ROOT (\w+)", line) or re.match(r"\s*JOINT\s+(\w+)", line)
-        if m:
-            names.append(m.group(1))
-            offsets.append([0.0, 0.0, 0.0])
-            parents.append(active)
-            active = len(parents) - 1
-            continue
-        if "{" in line:
-            continue
-        if "}" in line:
-            if end_site:
-                end_site = False
-            else:
-                active = parents[active]
-            continue
-        m = re.match(r"\s*OFFSET\s+([\-\d\.e]+)\s+([\-\d\.e]+)\s+([\-\d\.e]+)", line)
-        if m:
-            if not end_site:
-                offsets[active] = [float(x) for x in m.groups()]
-            continue
-        m = re.match(r"\s*CHANNELS\s+(\d+)", line)
-        if m:
-            channels = int(m.group(1))
-            if order is None:
-                lo, hi = (0, 3) if channels == 3 else (3, 6)
-                parts = line.split()[2 + lo:2 + hi]
-                if all(p in _CHANNEL for p in parts):
-                    order = tuple(_CHANNEL[p] for p in parts)
-            continue
-        if "End Site" in line:
-            end_site = True
-            continue
-        m = re.match(r"\s*Frames:\s+(\d+)", line)
-        if m:
-            fnum = int(m.group(1))
-            continue
-        m = re.match(r"\s*Frame Time:\s+([\d\.]+)", line)
-        if m:
-            frametime = float(m.group(1))
-            break
-    if fnum is None or order is None or channels is None or not names:
-        raise ValueError(f"{filename}: not a BVH file this loader understands")
+    names, parents, offsets, chan, order, fnum, frametime, moff = _parse_header(raw, filename)
+    motion_block = raw[moff:]
+    channels = int(chan[-1])  # the reference shapes the motion rows by the LAST joint's channel count (extract.py:104-106)
+    if (channels == 3 and (chan[0] not in (3, 6) or np.any(chan[1:] != 3))) or (channels == 6 and np.any(chan != 6)):
+        raise NotImplementedError(f"{filename}: joints with mixed channel counts are not supported")
     J = len(names)
     data = _parse_motion(motion_block, fnum, 9 * J + 3, filename)  # the ctypes call releases the GIL: files parse in parallel threads
     offs = np.asarray(offsets, dtype=np.float64)
     positions = np.repeat(offs[None], fnum, axis=0)
+    if channels == 3 and chan[0] == 3:  # a root without translation channels: the reference reads its first three columns as one anyway
+        raise NotImplementedError(f"{filename}: a 3-channel root is not supported")
     if channels == 3:
         if data.shape[1] != 3 + 3 * J:
             raise ValueError(f"{filename}: expected {3 + 3 * J} columns, found {data.shape[1]}")

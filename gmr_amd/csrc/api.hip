@@ -20,6 +20,7 @@
 #include "fk_kernel.hip.h"
 #include "ik_kernel.hip.h"
 #include "smplx_kernel.hip.h"
+#include "bvh_text.h"
 
 using gmr::u64;
 
@@ -1117,6 +1118,31 @@ int gmr_smplx_keypoints(const int32_t *parents, int n_joints, int joints_stride,
   hipLaunchKernelGGL(gmr::smplx_keypoints_kernel, dim3((unsigned)nblk), dim3(128), 0, static_cast<hipStream_t>(stream), sk, global_orient,
                      full_pose, joints, n_frames, n_frames_out, pos_out, quat_out);
   return hipGetLastError() == hipSuccess ? GMR_OK : GMR_EDEVICE;
+}
+
+int gmr_bvh_parse_header(const char *text, size_t len, int max_joints, char *names_out, size_t names_cap, int32_t *parents_out,
+                         double *offsets_out, int32_t *channels_out, int32_t *order_out, int64_t *n_frames_out, double *frame_time_out,
+                         size_t *motion_offset_out) {
+  if (!text || max_joints <= 0 || !names_out || !parents_out || !offsets_out || !channels_out || !order_out || !n_frames_out ||
+      !frame_time_out || !motion_offset_out)
+    return -1;
+  gmr_bvh::Cursor c{text, text + len};
+  gmr_bvh::Header h{max_joints, names_out, names_cap};
+  h.parents = parents_out; h.offsets = offsets_out; h.channels = channels_out;
+  if (!c.next() || !c.is("HIERARCHY") || !c.next() || !c.is("ROOT")) return -1;
+  int rc = gmr_bvh::joint(c, h, -1, 0);
+  if (rc) return rc;
+  int64_t nf;
+  double ft;
+  if (!c.next() || !c.is("MOTION") || !c.next() || !c.is("Frames:") || !gmr_bvh::integer(c, nf) || !c.next() || !c.is("Frame") ||
+      !c.next() || !c.is("Time:") || !gmr_bvh::number(c, ft))
+    return -1;
+  const char *p = c.p;  // the motion rows start behind the end of the Frame Time line
+  while (p < text + len && *p != '\n') ++p;
+  if (p < text + len) ++p;
+  for (int i = 0; i < 3; ++i) order_out[i] = h.order[i];
+  *n_frames_out = nf; *frame_time_out = ft; *motion_offset_out = (size_t)(p - text);
+  return h.n;
 }
 
 int64_t gmr_bvh_parse_motion(const char *text, size_t len, int64_t max_lines, double *out, int64_t max_out, int64_t *n_lines,

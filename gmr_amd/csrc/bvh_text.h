@@ -1,0 +1,125 @@
+// bvh_text.h -- host-side tokenizer for the HIERARCHY section and MOTION header of a BVH file (gmr_bvh_parse_header).
+//
+// Replaces the line-by-line hierarchy loop of the reference's read_bvh (general_motion_retargeting/utils/lafan_vendor/
+// extract.py:60-139) with a recursive-descent parser over whitespace-separated tokens; line structure is irrelevant.
+//
+//   file     := "HIERARCHY" joint "MOTION" "Frames:" INT "Frame" "Time:" NUM  <motion rows>
+//   joint    := ("ROOT" | "JOINT") NAME "{" "OFFSET" NUM NUM NUM "CHANNELS" INT CHANNEL{INT} (joint | endsite)* "}"
+//   endsite  := "End" "Site" "{" "OFFSET" NUM NUM NUM "}"
+//   CHANNEL  := ("X" | "Y" | "Z") ("position" | "rotation")
+//
+// Semantics kept from the reference so that files load identically: joints are numbered in the order they appear; an
+// end site contributes nothing; the Euler order is read off the LAST three channels of the FIRST joint (:107-113), which
+// must be rotations; the per-joint channel count that shapes the motion rows is the LAST joint's (:104-106), reported per
+// joint here so the caller can reject mixed files it cannot lay out; NAME keeps the leading run of [A-Za-z0-9_] of its token
+// (the reference captures `\w+`); numbers are decimal literals rounded like Python's float() (strtod).
+#pragma once
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+
+namespace gmr_bvh {
+
+struct Cursor {
+  const char *p, *end;
+  const char *tok = nullptr;
+  size_t len = 0;
+  bool next() {  // advance to the next whitespace-separated token
+    while (p < end && (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n')) ++p;
+    if (p >= end) { tok = nullptr; len = 0; return false; }
+    tok = p;
+    while (p < end && !(*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n')) ++p;
+    len = (size_t)(p - tok);
+    return true;
+  }
+  bool is(const char *s) const { return tok && len == strlen(s) && memcmp(tok, s, len) == 0; }
+};
+
+struct Header {
+  int max_joints; char *names; size_t names_cap, names_used = 0;
+  int32_t *parents; double *offsets; int32_t *channels; int32_t order[3] = {-1, -1, -1};
+  int n = 0;
+};
+
+inline bool number(Cursor &c, double &v) {
+  if (!c.next() || c.len == 0 || c.len > 63) return false;
+  char buf[64];
+  memcpy(buf, c.tok, c.len);
+  buf[c.len] = 0;
+  char *e = nullptr;
+  v = strtod(buf, &e);
+  return e == buf + c.len;
+}
+inline bool integer(Cursor &c, int64_t &v) {
+  if (!c.next() || c.len == 0 || c.len > 18) return false;
+  v = 0;
+  for (size_t i = 0; i < c.len; ++i) {
+    if (c.tok[i] < '0' || c.tok[i] > '9') return false;
+    v = v * 10 + (c.tok[i] - '0');
+  }
+  return true;
+}
+inline bool offset3(Cursor &c, double *dst) {  // "OFFSET" already consumed
+  double v[3];
+  for (int i = 0; i < 3; ++i)
+    if (!number(c, v[i])) return false;
+  if (dst) { dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; }
+  return true;
+}
+
+// c.tok is "ROOT" or "JOINT".  Returns 0 ok, -1 malformed, -2 capacity.
+inline int joint(Cursor &c, Header &h, int parent, int depth) {
+  if (depth > 256) return -1;
+  if (!c.next()) return -1;
+  size_t nl = 0;
+  while (nl < c.len && ((c.tok[nl] >= 'a' && c.tok[nl] <= 'z') || (c.tok[nl] >= 'A' && c.tok[nl] <= 'Z') || (c.tok[nl] >= '0' && c.tok[nl] <= '9') || c.tok[nl] == '_')) ++nl;
+  if (nl == 0) return -1;
+  if (h.n >= h.max_joints || h.names_used + nl + 1 > h.names_cap) return -2;
+  const int me = h.n++;
+  memcpy(h.names + h.names_used, c.tok, nl);
+  h.names[h.names_used + nl] = 0;
+  h.names_used += nl + 1;
+  h.parents[me] = parent;
+  h.offsets[3 * me] = h.offsets[3 * me + 1] = h.offsets[3 * me + 2] = 0.0;
+  h.channels[me] = 0;
+  if (!c.next() || !c.is("{")) return -1;
+  bool have_offset = false, have_channels = false;
+  while (c.next()) {
+    if (c.is("}")) return have_channels ? 0 : -1;
+    if (c.is("OFFSET")) {
+      if (!offset3(c, h.offsets + 3 * me)) return -1;
+      have_offset = true;
+    } else if (c.is("CHANNELS")) {
+      int64_t k;
+      if (have_channels || !integer(c, k) || k < 0 || k > 9) return -1;
+      int axes[9];
+      for (int i = 0; i < (int)k; ++i) {
+        if (!c.next() || c.len != 9 || c.tok[0] < 'X' || c.tok[0] > 'Z') return -1;
+        const bool rot = memcmp(c.tok + 1, "rotation", 8) == 0, pos = memcmp(c.tok + 1, "position", 8) == 0;
+        if (!rot && !pos) return -1;
+        axes[i] = rot ? c.tok[0] - 'X' : -1;
+      }
+      h.channels[me] = (int32_t)k;
+      have_channels = true;
+      if (me == 0) {  // Euler order: the last three channels of the first joint
+        if (k < 3) return -1;
+        for (int i = 0; i < 3; ++i) {
+          if (axes[k - 3 + i] < 0) return -1;
+          h.order[i] = axes[k - 3 + i];
+        }
+      }
+    } else if (c.is("JOINT")) {
+      int rc = joint(c, h, me, depth + 1);
+      if (rc) return rc;
+    } else if (c.is("End")) {
+      if (!c.next() || !c.is("Site") || !c.next() || !c.is("{") || !c.next() || !c.is("OFFSET") || !offset3(c, nullptr) || !c.next() || !c.is("}"))
+        return -1;
+    } else {
+      return -1;
+    }
+  }
+  (void)have_offset;
+  return -1;  // ran out of text inside a joint
+}
+
+}  // namespace gmr_bvh

@@ -301,7 +301,10 @@ class Engine:
         self._check(rc, "gmr_evaluate")
         return (err, xp, xq, terr) if want_task_errors else (err, xp, xq)
 
-    def fk(self, root_pos: torch.Tensor, root_rot_xyzw: torch.Tensor, dof: torch.Tensor, want_rot: bool = True):
+    def fk(self, root_pos: torch.Tensor, root_rot_xyzw: torch.Tensor, dof: torch.Tensor, want_rot: bool = True,
+           out_pos: Optional[torch.Tensor] = None, out_rot: Optional[torch.Tensor] = None):
+        """``KinematicsModel.forward_kinematics``: body_pos [T,nbody,3] (and body_rot [T,nbody,4] xyzw), float32.  ``out_pos`` /
+        ``out_rot``: caller-owned result tensors (a fresh multi-GB allocation costs more than the kernel)."""
         for t in (root_pos, root_rot_xyzw, dof):
             if t.device != self.device or t.dtype != torch.float32:
                 raise EngineError("fk inputs must be float32 tensors on the engine's device")
@@ -309,8 +312,14 @@ class Engine:
         if root_pos.shape != (T, 3) or root_rot_xyzw.shape != (T, 4) or dof.shape != (T, self.nq - 7):
             raise EngineError("bad fk input shapes")
         root_pos, root_rot_xyzw, dof = root_pos.contiguous(), root_rot_xyzw.contiguous(), dof.contiguous()
-        bp = torch.empty((T, self.nbody, 3), dtype=torch.float32, device=self.device)
-        br = torch.empty((T, self.nbody, 4), dtype=torch.float32, device=self.device) if want_rot else None
+        def _out(t, k):
+            if t is None:
+                return torch.empty((T, self.nbody, k), dtype=torch.float32, device=self.device)
+            if t.shape != (T, self.nbody, k) or t.dtype != torch.float32 or t.device != self.device or not t.is_contiguous():
+                raise EngineError("fk output tensors must be contiguous float32 [T, nbody, 3 / 4] on the engine's device")
+            return t
+        bp = _out(out_pos, 3)
+        br = _out(out_rot, 4) if want_rot else None
         rc = self._lib.gmr_fk(self._h, _ptr(root_pos), _ptr(root_rot_xyzw), _ptr(dof), T, _ptr(bp), _ptr(br), self._stream())
         self._check(rc, "gmr_fk")
         return bp, br

@@ -32,6 +32,7 @@
  *                      (scripts/smplx_to_robot_dataset.py:118-126)
  *   gmr_smplx_keypoints the numeric part of get_smplx_data_offline_fast (general_motion_retargeting/utils/smpl.py:109-198)
  *                      after the SMPL-X body model: slerp/lerp to the target frame rate, orientation chaining
+ *   gmr_bvh_parse_header the HIERARCHY section of read_bvh (general_motion_retargeting/utils/lafan_vendor/extract.py:60-139)
  *   gmr_bvh_parse_motion the MOTION block of read_bvh (general_motion_retargeting/utils/lafan_vendor/extract.py:140-166): the
  *                      per-line regex + float() loop that dominates BVH loading in the reference
  *   gmr_bvh_fk         the numeric part of load_lafan1_file (general_motion_retargeting/utils/lafan1.py:8-40):
@@ -155,6 +156,20 @@ int gmr_fk_min_height(gmr_model *m, const float *root_pos, const float *root_rot
 int gmr_smplx_keypoints(const int32_t *parents, int n_joints, int joints_stride, const double *global_orient, const double *full_pose,
                         const double *joints, int64_t n_frames, int64_t n_frames_out, int resample, double *pos_out, double *quat_out,
                         void *stream);
+
+/* Host-side parse of a BVH file's HIERARCHY section and MOTION header (stateless, no device involved; grammar and the
+ * reference semantics it keeps are documented in gmr_amd/csrc/bvh_text.h).  Replaces the hierarchy loop of read_bvh
+ * (general_motion_retargeting/utils/lafan_vendor/extract.py:60-139).
+ *   text/len        the file (or at least its header)
+ *   names_out       host char[names_cap]: joint names, NUL-separated, in hierarchy order
+ *   parents_out     host int32[max_joints] (-1 for the root); offsets_out host double[max_joints][3]
+ *   channels_out    host int32[max_joints]: channel count of every joint
+ *   order_out       host int32[3]: axis (0=x,1=y,2=z) of the first joint's last three channels, in listed order
+ *   n_frames_out, frame_time_out: the MOTION header; motion_offset_out: byte offset of the first motion row in text
+ * Returns the number of joints, -1 on a malformed file, -2 if max_joints / names_cap are too small.                      */
+int gmr_bvh_parse_header(const char *text, size_t len, int max_joints, char *names_out, size_t names_cap, int32_t *parents_out,
+                         double *offsets_out, int32_t *channels_out, int32_t *order_out, int64_t *n_frames_out, double *frame_time_out,
+                         size_t *motion_offset_out);
 
 /* Host-side text parse of a BVH MOTION block (stateless, no device involved): the first max_lines non-empty lines of
  * text[0..len) are read as whitespace-separated decimal numbers into out (host, capacity max_out doubles), correctly
