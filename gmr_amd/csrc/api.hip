@@ -755,13 +755,16 @@ int build_device_model(gmr_model *m) {
   gmr::FkTree &fk = m->fk;
   fk.parent = DP(int, o_parent); fk.dofidx = DP(int, o_dofidx); fk.src_slot = DP(int, o_src); fk.save_slot = DP(int, o_save);
   fk.lpos = DP(float, o_lpos); fk.lrot = DP(float, o_lrot); fk.jaxis = DP(float, o_jaxis); fk.jaxis64 = DP(double, o_jaxis64);
-  fk.nbody = nb; fk.ndof = nq - 7; fk.nslots = nslots; fk.pad = 0;
+  fk.nbody = nb; fk.ndof = nq - 7; fk.nslots = nslots;
+  fk.dof_in_order = 1;
+  for (int b = 0, prev = -1; b < nb; ++b)
+    if (dofidx[b] >= 0) { if (dofidx[b] < prev) fk.dof_in_order = 0; prev = dofidx[b]; }
 #undef DP
   memcpy(P.buf.data() + o_dm, &dm, sizeof(dm));
   HIP_TRY(m, hipMemcpy(m->dev, P.buf.data(), P.buf.size(), hipMemcpyHostToDevice));
   // branch slots + dof tile + position / rotation stages (fk_kernel.hip.h)
-  m->fk_lds_bytes = (std::max(1, nslots) * 7 + std::max(1, nq - 7) + gmr::kFkPosStride + gmr::kFkRotStride) * gmr::kFkThreads * (int)sizeof(float);
-  m->fk_lds_bytes_min = (std::max(1, nslots) * 7 + std::max(1, nq - 7)) * gmr::kFkThreads * (int)sizeof(float);
+  m->fk_lds_bytes = (std::max(1, nslots) * 7 + gmr::kFkPosStride + gmr::kFkRotStride) * gmr::kFkThreads * (int)sizeof(float);
+  m->fk_lds_bytes_min = std::max(1, nslots) * 7 * gmr::kFkThreads * (int)sizeof(float);
 
   if (m->lds_bytes > 160 * 1024) { set_err(m, "model needs %d bytes of LDS per wavefront", m->lds_bytes); return GMR_EUNSUPPORTED; }
   // opt in to > 64 KiB of dynamic LDS where a variant needs it

@@ -8,11 +8,15 @@
 // (SGPRs); the chain itself runs in VGPRs.  Bodies are in depth-first order, so a body's parent is either
 // the previous body (pose still in registers) or an earlier branch point whose pose was parked in a
 // per-lane LDS slot (slot lifetimes planned on the host).
-// HBM access is tile-wise, not per lane: a workgroup's frames are contiguous rows of every array, so the
-// dof rows come in as one coalesced copy into LDS, and the poses go out through an LDS stage, kFkGroup
-// bodies at a time, as runs of kFkGroup x 12 (16) contiguous bytes per frame written by consecutive lanes.
-// (With one lane storing its own frame directly, every store instruction touched 64 different cache lines
-// and the kernel sat at the L2 request rate, 9 % of the HBM roofline.)
+// The poses go out through an LDS stage, kFkGroup bodies at a time, as runs of kFkGroup x 12 (16) contiguous
+// bytes per frame written by consecutive lanes.  (With one lane storing its own frame directly, every store
+// instruction touched 64 different cache lines and the kernel sat at the L2 request rate, 9 % of the HBM
+// roofline.)  The dof row of a lane's frame is read by the lane itself, four consecutive angles per 16-byte
+// load into a register window that slides down the row one group ahead of its use (hinges are numbered in
+// body order, so the chain consumes the row front to back): 8 L2 requests per frame instead of 29, and no
+// LDS -- the dof tile of round 1 (116 B per lane for G1) was what held the kernel at 1.5 waves per SIMD, where
+// the dependent chain of every body is exposed latency.  LDS per lane is now the branch slots (2 for G1: 56 B)
+// and the output stage (100 B): 8 workgroups = 16 waves per CU.
 // Algorithmic HBM traffic per frame: (3+4+ndof) x 4 B in, nbody x 12 B out (+ nbody x 16 B if rotations
 // are requested).
 #pragma once
@@ -39,7 +43,7 @@ struct FkTree {     // device arrays, [nbody]
   const float *lrot;   // [nb][4] local rotation xyzw, raw XML values (not normalised)
   const float *jaxis;  // [nb][3] hinge axis, unit (double normalised, then rounded)
   const double *jaxis64;  // [nb][3] unit axis in float64 (torch promotes the hinge quaternion to float64)
-  int nbody, ndof, nslots, pad;
+  int nbody, ndof, nslots, dof_in_order;  // dof_in_order: dofidx never decreases along the bodies (the register window needs it)
 };
 
 __device__ __forceinline__ void fk_quat_mul(const float a[4], const float b[4], float o[4]) {
@@ -65,8 +69,17 @@ __device__ __forceinline__ void fk_quat_rotate(const float q[4], const float v[3
 }
 
 // MODE 0: write body_pos (and body_rot if non-null).  MODE 1: per-clip min of z (atomics on an ordered-int key).
-// Dynamic LDS (floats): [nslots][7][kFkThreads] branch slots | [kFkThreads][ndof] dof tile |
+// Dynamic LDS (floats): [nslots][7][kFkThreads] branch slots |
 //                       [kFkThreads][kFkPosStride] position stage | [kFkThreads][kFkRotStride] rotation stage (MODE 0)
+// The tree arrays are read-only for the whole launch, but the kernel also stores to global memory, so the compiler will not
+// prove them invariant by itself and reads them with per-lane VMEM loads (a full memory round trip in front of every
+// wave-uniform branch of the chain).  Reading them through the constant address space makes them scalar loads: SGPR
+// results, scalar branches, the scalar cache.
+template <class T>
+__device__ __forceinline__ T fk_const(const T *p, int i) {
+  return (reinterpret_cast<const T __attribute__((address_space(4))) *>(reinterpret_cast<uintptr_t>(p)))[i];
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(kFkThreads) fk_kernel(FkTree t, const float *__restrict__ root_pos,
                                                         const float *__restrict__ root_rot, const float *__restrict__ dof,
@@ -83,30 +96,29 @@ __global__ void __launch_bounds__(kFkThreads) fk_kernel(FkTree t, const float *_
   const bool live = tid < nfb;
   const int64_t fc = live ? f : n_frames - 1;  // clamp: dead lanes recompute the last frame, never store
   float *slots = fk_lds;
-  float *dtile = slots + (size_t)t.nslots * 7 * kFkThreads;
-  float *pstage = dtile + (size_t)kFkThreads * ndof;
+  float *pstage = slots + (size_t)t.nslots * 7 * kFkThreads;
   float *rstage = pstage + kFkThreads * kFkPosStride;
-  // dof tile: rows f0 .. f0+nfb-1 are contiguous in memory -> one coalesced copy
-  {
-    const float *src = dof + f0 * ndof;
-    const int n = nfb * ndof;
-    for (int i = tid; i < n; i += kFkThreads) dtile[i] = src[i];
-  }
+  // dof row of this lane's frame: a window of four consecutive angles in registers, the next window already in flight
+  struct D4 { float v[4]; };  // 16 bytes, 4-byte aligned (rows start on dword boundaries only)
+  const float *myrow = dof + fc * ndof;
+  const bool windowed = ndof >= 4 && t.dof_in_order;
+  const int last_start = ndof - 4;
+  D4 dwin{{0.f, 0.f, 0.f, 0.f}}, dnext{{0.f, 0.f, 0.f, 0.f}};
+  int win_group = -1;  // group (di >> 2) held by dwin; dnext holds win_group + 1
+  if (windowed) dnext = *reinterpret_cast<const D4 *>(myrow);
   float cp[3], cr[4];
 #pragma unroll
   for (int i = 0; i < 3; i++) cp[i] = root_pos[fc * 3 + i];
 #pragma unroll
   for (int i = 0; i < 4; i++) cr[i] = root_rot[fc * 4 + i];
   float zmin = cp[2];
-  if (t.save_slot[0] >= 0) {
-    float *s = slots + (size_t)t.save_slot[0] * 7 * kFkThreads + tid;
+  if (fk_const(t.save_slot, 0) >= 0) {
+    float *s = slots + (size_t)fk_const(t.save_slot, 0) * 7 * kFkThreads + tid;
 #pragma unroll
     for (int i = 0; i < 3; i++) s[i * kFkThreads] = cp[i];
 #pragma unroll
     for (int i = 0; i < 4; i++) s[(3 + i) * kFkThreads] = cr[i];
   }
-  __syncthreads();  // dof tile complete
-  const float *mydof = dtile + (live ? tid : nfb - 1) * ndof;
   const bool want_rot = MODE == 0 && body_rot != nullptr;
   // flush the stage: bodies j0 .. j0+cnt-1 of every frame of the workgroup, consecutive lanes -> consecutive words
   struct F3 { float x, y, z; };  // 12 bytes, 4-byte aligned: one global_store_dwordx3 per body
@@ -142,7 +154,7 @@ __global__ void __launch_bounds__(kFkThreads) fk_kernel(FkTree t, const float *_
   for (int j = 1; j < nbody; ++j) {
     if (MODE == 0 && (j % kFkGroup) == 0) flush_n(j - kFkGroup, std::integral_constant<int, kFkGroup>{});
     float pp[3], pr[4];
-    const int src = t.src_slot[j];
+    const int src = fk_const(t.src_slot, j);
     if (src < 0) {
 #pragma unroll
       for (int i = 0; i < 3; i++) pp[i] = cp[i];
@@ -156,14 +168,29 @@ __global__ void __launch_bounds__(kFkThreads) fk_kernel(FkTree t, const float *_
       for (int i = 0; i < 4; i++) pr[i] = s[(3 + i) * kFkThreads];
     }
     float jq[4] = {0.f, 0.f, 0.f, 1.f};
-    const int di = t.dofidx[j];
+    const int di = fk_const(t.dofidx, j);
     if (di >= 0) {
       // axis_angle_to_quat: sin/cos in float32, the product with the float64 axis and the renormalisation in float64
-      const float th = mydof[di] / 2.0f;
+      float ang;
+      if (windowed) {  // (all conditions wave-uniform: the tree is)
+        const int g = di >> 2;
+        while (win_group < g) {  // slide: hinges come in row order, so this advances by one group at a time
+          dwin = dnext;
+          ++win_group;
+          const int nxt = 4 * (win_group + 1);
+          if (nxt < ndof) dnext = *reinterpret_cast<const D4 *>(myrow + (nxt < last_start ? nxt : last_start));
+        }
+        const int start = 4 * g < last_start ? 4 * g : last_start;
+        const int k = di - start;
+        ang = k == 0 ? dwin.v[0] : k == 1 ? dwin.v[1] : k == 2 ? dwin.v[2] : dwin.v[3];
+      } else {
+        ang = myrow[di];
+      }
+      const float th = ang / 2.0f;
       float sf, cf;
       sincosf(th, &sf, &cf);  // one range reduction for both; same values as sinf / cosf
       const double s = (double)sf, c = (double)cf;
-      const double qx = t.jaxis64[3 * j] * s, qy = t.jaxis64[3 * j + 1] * s, qz = t.jaxis64[3 * j + 2] * s;
+      const double qx = fk_const(t.jaxis64, 3 * j) * s, qy = fk_const(t.jaxis64, 3 * j + 1) * s, qz = fk_const(t.jaxis64, 3 * j + 2) * s;
       // / max(|q|, 1e-9) in float64: |q| = 1 to float32 rounding here (unit axis, sin^2 + cos^2), so the clamp never binds and
       // a Newton-refined reciprocal square root (<= 1 ulp in float64, invisible after the cast to float32) replaces sqrt + 4 divides
       const double n2 = qx * qx + qy * qy + qz * qz + c * c;
@@ -173,8 +200,8 @@ __global__ void __launch_bounds__(kFkThreads) fk_kernel(FkTree t, const float *_
       r = n2 < 1e-18 ? 1e9 : r;
       jq[0] = (float)(qx * r); jq[1] = (float)(qy * r); jq[2] = (float)(qz * r); jq[3] = (float)(c * r);
     }
-    const float lt[3] = {t.lpos[3 * j], t.lpos[3 * j + 1], t.lpos[3 * j + 2]};
-    const float lr[4] = {t.lrot[4 * j], t.lrot[4 * j + 1], t.lrot[4 * j + 2], t.lrot[4 * j + 3]};
+    const float lt[3] = {fk_const(t.lpos, 3 * j), fk_const(t.lpos, 3 * j + 1), fk_const(t.lpos, 3 * j + 2)};
+    const float lr[4] = {fk_const(t.lrot, 4 * j), fk_const(t.lrot, 4 * j + 1), fk_const(t.lrot, 4 * j + 2), fk_const(t.lrot, 4 * j + 3)};
     float wt[3], tmp[4];
     fk_quat_rotate(pr, lt, wt);
 #pragma unroll
@@ -183,7 +210,7 @@ __global__ void __launch_bounds__(kFkThreads) fk_kernel(FkTree t, const float *_
     fk_quat_mul(pr, tmp, cr);
     if (MODE == 0) stage(j % kFkGroup);
     else zmin = fminf(zmin, cp[2]);
-    const int sv = t.save_slot[j];
+    const int sv = fk_const(t.save_slot, j);
     if (sv >= 0) {
       float *s = slots + (size_t)sv * 7 * kFkThreads + tid;
 #pragma unroll

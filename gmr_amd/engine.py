@@ -128,17 +128,18 @@ class Engine:
         return out, iters, qfin
 
     def ik_solve_host(self, pos: np.ndarray, quat: np.ndarray, slot_col: np.ndarray, seq_offsets, params: Optional[IKParams] = None,
-                      height_scales=None, batch_frames: int = 1 << 20, want_iters: bool = True, check: bool = True):
+                      height_scales=None, min_batch_clips: int = 2048, max_batches: int = 4, want_iters: bool = True, check: bool = True):
         """Whole clips from HOST arrays to a HOST result, pipelined: what the dataset scripts hand over
         (scripts/smplx_to_robot_dataset.py:84-89 builds host key-points per file) without a serial copy-in / solve / copy-out.
 
-        Clips are grouped into batches of about ``batch_frames`` frames.  Two HIP streams, each with its own pinned staging
-        buffer and device buffers: while stream A's batch is in flight (H2D of 392 B/frame, kernel, D2H of 288 B/frame straight
-        into the pinned result), the host fills stream B's staging buffer with the next batch -- only the columns the config
-        consumes are staged (14 of 55 SMPL-X joints).  Results are bitwise those of ``ik_solve`` on resident tensors (same
-        kernel, same per-clip work items).  With ``check`` every batch is inspected on the device (non-finite qpos ->
-        FloatingPointError, a capped QP -> RuntimeError).  Returns (qpos [N, nq] float64, iters [N] int32 or None) as numpy
-        arrays backed by pinned memory.
+        Clips are grouped into up to ``max_batches`` batches of at least ``min_batch_clips`` clips (one wavefront per clip:
+        a batch should fill the chip's 2048 wavefront slots).  Batches alternate between two HIP streams, each with its own
+        device buffers: batch k+1's key-points cross PCIe (the caller's pageable arrays are read in place -- all their columns;
+        ``slot_col`` picks the ones the config consumes on the device) while batch k's kernel runs, and every batch's qpos goes
+        straight into a pinned host result (a fresh pageable result array would cost more in page faults than the kernel takes).
+        Results are bitwise those of ``ik_solve`` on resident tensors (same kernel, same per-clip work items).  With ``check``
+        every batch is inspected on the device (non-finite qpos -> FloatingPointError, a capped QP -> RuntimeError).  Returns
+        (qpos [N, nq] float64, iters [N] int32 or None) as numpy arrays backed by pinned memory.  Measured rates: DESIGN.md.
         """
         from .schedule import make_items
         if pos.dtype != quat.dtype or pos.dtype not in (np.float32, np.float64):
@@ -146,55 +147,46 @@ class Engine:
         if pos.ndim != 3 or quat.ndim != 3 or pos.shape[2] != 3 or quat.shape[2] != 4 or pos.shape[:2] != quat.shape[:2]:
             raise EngineError(f"bad input shapes {pos.shape} / {quat.shape}")
         offs = np.asarray(seq_offsets, dtype=np.int64)
-        N, ns = int(pos.shape[0]), self.info.nslot
+        N, B = int(pos.shape[0]), int(pos.shape[1])
         if offs[0] != 0 or offs[-1] != N:
             raise EngineError("seq_offsets must span [0, N]")
         slot_col = np.ascontiguousarray(slot_col, dtype=np.int32)
-        cols_t = torch.from_numpy(slot_col.astype(np.int64))
-        ident = np.arange(ns, dtype=np.int32)
         tdt = torch.float32 if pos.dtype == np.float32 else torch.float64
         hs = None if height_scales is None else np.asarray(height_scales, dtype=np.float64)
-        # batches of whole clips
-        bounds = [0]
-        for s in range(len(offs) - 1):
-            if offs[s + 1] - offs[bounds[-1]] >= batch_frames and s + 1 < len(offs) - 1:
-                bounds.append(s + 1)
-        bounds.append(len(offs) - 1)
-        cap = max(int(offs[bounds[k + 1]] - offs[bounds[k]]) for k in range(len(bounds) - 1)) if N else 0
         out = torch.empty((N, self.nq), dtype=torch.float64, pin_memory=True)
         iters = torch.empty(N, dtype=torch.int32, pin_memory=True) if want_iters else None
         if N == 0:
             return out.numpy(), (iters.numpy() if want_iters else None)
-        tpos, tquat = torch.from_numpy(pos), torch.from_numpy(quat)
+        n_clips = len(offs) - 1
+        nb = max(1, min(max_batches, n_clips // max(1, min_batch_clips)))
+        bounds = sorted({int(np.searchsorted(offs, N * k / nb, side="left")) for k in range(nb)} | {n_clips})
+        if bounds[0] != 0:
+            bounds = [0] + bounds
+        cap = max(int(offs[bounds[k + 1]] - offs[bounds[k]]) for k in range(len(bounds) - 1))
+        tpos, tquat = torch.from_numpy(np.ascontiguousarray(pos)), torch.from_numpy(np.ascontiguousarray(quat))
         nbuf = min(2, len(bounds) - 1)
         st = [torch.cuda.Stream(self.device) for _ in range(nbuf)]
-        hp = [torch.empty((cap, ns, 3), dtype=tdt, pin_memory=True) for _ in range(nbuf)]
-        hq = [torch.empty((cap, ns, 4), dtype=tdt, pin_memory=True) for _ in range(nbuf)]
-        dp = [torch.empty((cap, ns, 3), dtype=tdt, device=self.device) for _ in range(nbuf)]
-        dq = [torch.empty((cap, ns, 4), dtype=tdt, device=self.device) for _ in range(nbuf)]
+        dp = [torch.empty((cap, B, 3), dtype=tdt, device=self.device) for _ in range(nbuf)]
+        dq = [torch.empty((cap, B, 4), dtype=tdt, device=self.device) for _ in range(nbuf)]
         do = [torch.empty((cap, self.nq), dtype=torch.float64, device=self.device) for _ in range(nbuf)]
-        di = [torch.empty(cap, dtype=torch.int32, device=self.device) for _ in range(nbuf)] if want_iters else None
-        staged = [None] * nbuf  # event: the H2D copies out of staging buffer b have completed
         want_i = want_iters or check
-        if check and di is None:
-            di = [torch.empty(cap, dtype=torch.int32, device=self.device) for _ in range(nbuf)]
+        di = [torch.empty(cap, dtype=torch.int32, device=self.device) for _ in range(nbuf)] if want_i else None
         flags = torch.zeros((nbuf, 2), dtype=torch.int32, device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        for s_ in st:
+            s_.wait_stream(cur)
         for k in range(len(bounds) - 1):
             b = k % nbuf
             c0, c1 = bounds[k], bounds[k + 1]
             f0, f1 = int(offs[c0]), int(offs[c1])
             n = f1 - f0
-            if staged[b] is not None:
-                staged[b].synchronize()
-            torch.index_select(tpos[f0:f1], 1, cols_t, out=hp[b][:n])
-            torch.index_select(tquat[f0:f1], 1, cols_t, out=hq[b][:n])
             items = make_items(offs[c0:c1 + 1] - f0, height_scales=None if hs is None else hs[c0:c1])
             with torch.cuda.stream(st[b]):
-                dp[b][:n].copy_(hp[b][:n], non_blocking=True)
-                dq[b][:n].copy_(hq[b][:n], non_blocking=True)
-                staged[b] = torch.cuda.Event()
-                staged[b].record()
-                self.ik_solve(dp[b][:n], dq[b][:n], ident, items, params=params, out=do[b][:n],
+                # pageable -> device: the runtime stages the copy and returns when the host data has been consumed; the other
+                # stream's kernel keeps running meanwhile
+                dp[b][:n].copy_(tpos[f0:f1], non_blocking=True)
+                dq[b][:n].copy_(tquat[f0:f1], non_blocking=True)
+                self.ik_solve(dp[b][:n], dq[b][:n], slot_col, items, params=params, out=do[b][:n],
                               iters=di[b][:n] if want_i else None, want_iters=want_i)
                 if check:
                     flags[b, 0] |= (~torch.isfinite(do[b][:n])).any().to(torch.int32)
@@ -204,6 +196,7 @@ class Engine:
                     iters[f0:f1].copy_(di[b][:n], non_blocking=True)
         for s_ in st:
             s_.synchronize()
+            cur.wait_stream(s_)
         if check:
             bad = flags.sum(0).cpu().numpy()
             if bad[0]:

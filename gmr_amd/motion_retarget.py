@@ -269,7 +269,7 @@ class GeneralMotionRetargeting:
         is_np = isinstance(pos, np.ndarray)
         cols = self._columns(list(body_names))  # KeyError where the reference raises
         if is_np and isinstance(quat, np.ndarray) and chunk == 0 and pos.ndim == 3 and pos.shape[0] >= self.HOST_PIPELINE_MIN_FRAMES:
-            # big host batches: pinned double-buffered pipeline, copies overlapped with the kernel (Engine.ik_solve_host)
+            # big host batches: two streams, copies overlapped with the kernel, pinned result (Engine.ik_solve_host)
             N = int(pos.shape[0])
             offs = np.asarray([0, N] if seq_offsets is None else seq_offsets, dtype=np.int64)
             hs = None
