@@ -42,6 +42,7 @@ struct gmr_model {
   gmr::LdsLayout lay{};
   int nvp = 0, n_act = 0, lds_bytes = 0, fk_lds_bytes = 0, fk_lds_bytes_min = 0;  // _min: the min-height mode has no output stage
   unsigned long long *dbg = nullptr;  // diagnostic builds (GMR_IK_STAMPS) only
+  int fk_pos_parts = 1;               // gmr_fk without rotations: fk_pos_kernel<parts> (GMR_AMD_FK_PARTS=0 falls back to fk_kernel<0>)
   bool force_generic = false;         // GMR_AMD_GENERIC_QP=1: use the dense generic QP even where the structured one applies
 };
 
@@ -830,6 +831,7 @@ gmr_model *gmr_model_create(const void *blob, size_t blob_bytes, int device, cha
       return fail(m, "stream-ordered memory pool unavailable on this device");
   }
   if (const char *e = getenv("GMR_AMD_GENERIC_QP")) m->force_generic = e[0] == '1';
+  if (const char *e = getenv("GMR_AMD_FK_PARTS")) m->fk_pos_parts = e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1;
   if (build_device_model(m) != GMR_OK) return fail(m, "model build failed");
   return m;
 }
@@ -1065,6 +1067,20 @@ int gmr_fk(gmr_model *m, const float *root_pos, const float *root_rot_xyzw, cons
   const int64_t nblk = (n_frames + gmr::kFkThreads - 1) / gmr::kFkThreads;
   if (nblk > 0x7fffffff) { set_err(m, "too many frames for one launch"); return GMR_EINVAL; }
   // the rotation stage is the last LDS region: a positions-only call does not allocate it (more workgroups per CU)
+  if (!body_rot_out && m->fk_pos_parts > 0) {  // positions only: one wavefront per tile, the whole tile image in LDS (fk_pos_kernel)
+    const int64_t nw = (n_frames + gmr::kFkWave - 1) / gmr::kFkWave;
+    if (nw > 0x7fffffff) { set_err(m, "too many frames for one launch"); return GMR_EINVAL; }
+    const int nb = m->fk.nbody, parts = m->fk_pos_parts, prow = parts == 1 ? 3 * nb : 3 * ((nb + parts - 1) / parts);
+    const int lds = (std::max(1, m->fk.nslots) * 7 + prow) * gmr::kFkWave * (int)sizeof(float);
+    if (parts == 1)
+      hipLaunchKernelGGL((gmr::fk_pos_kernel<1>), dim3((unsigned)nw), dim3(gmr::kFkWave), lds, static_cast<hipStream_t>(stream), m->fk, root_pos,
+                         root_rot_xyzw, dof, n_frames, body_pos_out);
+    else
+      hipLaunchKernelGGL((gmr::fk_pos_kernel<2>), dim3((unsigned)nw), dim3(gmr::kFkWave), lds, static_cast<hipStream_t>(stream), m->fk, root_pos,
+                         root_rot_xyzw, dof, n_frames, body_pos_out);
+    HIP_TRY(m, hipGetLastError());
+    return GMR_OK;
+  }
   const int fk_lds = body_rot_out ? m->fk_lds_bytes : m->fk_lds_bytes - gmr::kFkRotStride * gmr::kFkThreads * (int)sizeof(float);
   hipLaunchKernelGGL((gmr::fk_kernel<0>), dim3((unsigned)nblk), dim3(gmr::kFkThreads), fk_lds, static_cast<hipStream_t>(stream), m->fk,
                      root_pos, root_rot_xyzw, dof, n_frames, body_pos_out, body_rot_out, (const int64_t *)nullptr, 0, (int *)nullptr);

@@ -80,6 +80,25 @@ __device__ __forceinline__ T fk_const(const T *p, int i) {
   return (reinterpret_cast<const T __attribute__((address_space(4))) *>(reinterpret_cast<uintptr_t>(p)))[i];
 }
 
+// axis_angle_to_quat (torch_utils.py:353-359 through kinematics_model.py:21-36): sin/cos in float32, the product with the
+// float64 axis and the renormalisation in float64, the result rounded to float32.
+__device__ __forceinline__ void fk_hinge_quat(const FkTree &t, int j, float ang, float jq[4]) {
+#pragma clang fp contract(off)
+  const float th = ang / 2.0f;
+  float sf, cf;
+  sincosf(th, &sf, &cf);  // one range reduction for both; same values as sinf / cosf
+  const double s = (double)sf, c = (double)cf;
+  const double qx = fk_const(t.jaxis64, 3 * j) * s, qy = fk_const(t.jaxis64, 3 * j + 1) * s, qz = fk_const(t.jaxis64, 3 * j + 2) * s;
+  // / max(|q|, 1e-9) in float64: |q| = 1 to float32 rounding here (unit axis, sin^2 + cos^2), so the clamp never binds and
+  // a Newton-refined reciprocal square root (<= 1 ulp in float64, invisible after the cast to float32) replaces sqrt + 4 divides
+  const double n2 = qx * qx + qy * qy + qz * qz + c * c;
+  double r = __builtin_amdgcn_rsq(n2);
+  r = r * (1.5 - 0.5 * n2 * r * r);
+  r = r * (1.5 - 0.5 * n2 * r * r);
+  r = n2 < 1e-18 ? 1e9 : r;
+  jq[0] = (float)(qx * r); jq[1] = (float)(qy * r); jq[2] = (float)(qz * r); jq[3] = (float)(c * r);
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(kFkThreads) fk_kernel(FkTree t, const float *__restrict__ root_pos,
                                                         const float *__restrict__ root_rot, const float *__restrict__ dof,
@@ -170,7 +189,6 @@ __global__ void __launch_bounds__(kFkThreads) fk_kernel(FkTree t, const float *_
     float jq[4] = {0.f, 0.f, 0.f, 1.f};
     const int di = fk_const(t.dofidx, j);
     if (di >= 0) {
-      // axis_angle_to_quat: sin/cos in float32, the product with the float64 axis and the renormalisation in float64
       float ang;
       if (windowed) {  // (all conditions wave-uniform: the tree is)
         const int g = di >> 2;
@@ -186,19 +204,7 @@ __global__ void __launch_bounds__(kFkThreads) fk_kernel(FkTree t, const float *_
       } else {
         ang = myrow[di];
       }
-      const float th = ang / 2.0f;
-      float sf, cf;
-      sincosf(th, &sf, &cf);  // one range reduction for both; same values as sinf / cosf
-      const double s = (double)sf, c = (double)cf;
-      const double qx = fk_const(t.jaxis64, 3 * j) * s, qy = fk_const(t.jaxis64, 3 * j + 1) * s, qz = fk_const(t.jaxis64, 3 * j + 2) * s;
-      // / max(|q|, 1e-9) in float64: |q| = 1 to float32 rounding here (unit axis, sin^2 + cos^2), so the clamp never binds and
-      // a Newton-refined reciprocal square root (<= 1 ulp in float64, invisible after the cast to float32) replaces sqrt + 4 divides
-      const double n2 = qx * qx + qy * qy + qz * qz + c * c;
-      double r = __builtin_amdgcn_rsq(n2);
-      r = r * (1.5 - 0.5 * n2 * r * r);
-      r = r * (1.5 - 0.5 * n2 * r * r);
-      r = n2 < 1e-18 ? 1e9 : r;
-      jq[0] = (float)(qx * r); jq[1] = (float)(qy * r); jq[2] = (float)(qz * r); jq[3] = (float)(c * r);
+      fk_hinge_quat(t, j, ang, jq);
     }
     const float lt[3] = {fk_const(t.lpos, 3 * j), fk_const(t.lpos, 3 * j + 1), fk_const(t.lpos, 3 * j + 2)};
     const float lr[4] = {fk_const(t.lrot, 4 * j), fk_const(t.lrot, 4 * j + 1), fk_const(t.lrot, 4 * j + 2), fk_const(t.lrot, 4 * j + 3)};
@@ -243,6 +249,133 @@ __global__ void __launch_bounds__(kFkThreads) fk_kernel(FkTree t, const float *_
     } else {
       atomicMin(min_key + lo, k);
     }
+  }
+}
+
+// ------------------------------------------------------------------ positions only: one wavefront per workgroup, no barriers
+// gmr_fk without rotations (what the dataset scripts call, scripts/smplx_to_robot_dataset.py:110-112) is bound by how the
+// poses leave the chip: flushed eight bodies at a time (fk_kernel above) every store covers 96-byte runs 456 bytes apart, i.e.
+// partial cache lines whose other parts arrive several flushes later -- by then the 4 MB L2 of the XCD (32 CUs x 8 workgroups x
+// 58 KB of output tiles in flight) has written them back partially.  Here a wavefront keeps the complete image of its output
+// tile (64 frames x nbody x 3 floats, contiguous in memory) in LDS and writes it once, linearly, 16 bytes per lane and store:
+// full lines only.  PARTS = 2 halves the LDS image (bodies in two passes) for twice the waves per CU at the price of one
+// shared line per frame between the two passes.  Same chain arithmetic as fk_kernel (identical results).
+constexpr int kFkWave = 64;
+
+struct FkD4 { float v[4]; };  // 16 bytes, 4-byte aligned
+
+template <int PARTS>
+__global__ void __launch_bounds__(kFkWave) fk_pos_kernel(FkTree t, const float *__restrict__ root_pos, const float *__restrict__ root_rot,
+                                                         const float *__restrict__ dof, int64_t n_frames, float *__restrict__ body_pos) {
+#pragma clang fp contract(off)
+  extern __shared__ float fk_lds[];
+  const int lane = threadIdx.x;
+  const int nbody = t.nbody, ndof = t.ndof, row = 3 * nbody;
+  const int64_t f0 = (int64_t)blockIdx.x * kFkWave;
+  const int nfb = (int)(n_frames - f0 < kFkWave ? n_frames - f0 : kFkWave);
+  const int64_t fc = lane < nfb ? f0 + lane : n_frames - 1;  // dead lanes recompute the last frame; their rows are not flushed
+  float *slots = fk_lds;
+  float *img = slots + (size_t)t.nslots * 7 * kFkWave;
+  const int hb = (nbody + PARTS - 1) / PARTS;  // bodies per part
+  const int prow = PARTS == 1 ? row : 3 * hb;   // words per frame in the LDS image
+  const float *myrow = dof + fc * ndof;
+  const bool windowed = ndof >= 4 && t.dof_in_order;
+  const int last_start = ndof - 4;
+  FkD4 dwin{{0.f, 0.f, 0.f, 0.f}}, dnext{{0.f, 0.f, 0.f, 0.f}};
+  int win_group = -1;
+  if (windowed) dnext = *reinterpret_cast<const FkD4 *>(myrow);
+  float cp[3], cr[4];
+#pragma unroll
+  for (int i = 0; i < 3; i++) cp[i] = root_pos[fc * 3 + i];
+#pragma unroll
+  for (int i = 0; i < 4; i++) cr[i] = root_rot[fc * 4 + i];
+  if (fk_const(t.save_slot, 0) >= 0) {
+    float *s = slots + (size_t)fk_const(t.save_slot, 0) * 7 * kFkWave + lane;
+#pragma unroll
+    for (int i = 0; i < 3; i++) s[i * kFkWave] = cp[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) s[(3 + i) * kFkWave] = cr[i];
+  }
+  auto flush_part = [&](int j0, int nb_part) {  // bodies j0 .. j0+nb_part-1 of the tile's nfb frames
+    __syncthreads();  // (one wavefront: orders the LDS writes of the other lanes before the reads below)
+    if (PARTS == 1) {
+      const int nwords = nfb * row, n4 = nwords >> 2;
+      float *dst = body_pos + f0 * row;  // 16-byte aligned: 64 rows of 12 nbody bytes per tile
+      for (int i = lane; i < n4; i += kFkWave)
+        *reinterpret_cast<float4 *>(dst + 4 * i) = *reinterpret_cast<const float4 *>(img + 4 * i);
+      for (int i = 4 * n4 + lane; i < nwords; i += kFkWave) dst[i] = img[i];
+    } else {
+      const int w = 3 * nb_part;
+      for (int fr = 0; fr < nfb; ++fr) {
+        float *dst = body_pos + (f0 + fr) * row + 3 * j0;
+        for (int o = lane; o < w; o += kFkWave) dst[o] = img[fr * prow + o];
+      }
+    }
+    __syncthreads();
+  };
+#pragma unroll
+  for (int i = 0; i < 3; i++) img[lane * prow + i] = cp[i];
+  for (int j = 1; j < nbody; ++j) {
+    if (PARTS > 1 && j % hb == 0) flush_part(j - hb, hb);
+    float pp[3], pr[4];
+    const int src = fk_const(t.src_slot, j);
+    if (src < 0) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) pp[i] = cp[i];
+#pragma unroll
+      for (int i = 0; i < 4; i++) pr[i] = cr[i];
+    } else {
+      const float *s = slots + (size_t)src * 7 * kFkWave + lane;
+#pragma unroll
+      for (int i = 0; i < 3; i++) pp[i] = s[i * kFkWave];
+#pragma unroll
+      for (int i = 0; i < 4; i++) pr[i] = s[(3 + i) * kFkWave];
+    }
+    float jq[4] = {0.f, 0.f, 0.f, 1.f};
+    const int di = fk_const(t.dofidx, j);
+    if (di >= 0) {
+      float ang;
+      if (windowed) {
+        const int g = di >> 2;
+        while (win_group < g) {
+          dwin = dnext;
+          ++win_group;
+          const int nxt = 4 * (win_group + 1);
+          if (nxt < ndof) dnext = *reinterpret_cast<const FkD4 *>(myrow + (nxt < last_start ? nxt : last_start));
+        }
+        const int start = 4 * g < last_start ? 4 * g : last_start;
+        const int k = di - start;
+        ang = k == 0 ? dwin.v[0] : k == 1 ? dwin.v[1] : k == 2 ? dwin.v[2] : dwin.v[3];
+      } else {
+        ang = myrow[di];
+      }
+      fk_hinge_quat(t, j, ang, jq);
+    }
+    const float lt[3] = {fk_const(t.lpos, 3 * j), fk_const(t.lpos, 3 * j + 1), fk_const(t.lpos, 3 * j + 2)};
+    const float lr[4] = {fk_const(t.lrot, 4 * j), fk_const(t.lrot, 4 * j + 1), fk_const(t.lrot, 4 * j + 2), fk_const(t.lrot, 4 * j + 3)};
+    float wt[3], tmp[4];
+    fk_quat_rotate(pr, lt, wt);
+#pragma unroll
+    for (int i = 0; i < 3; i++) cp[i] = pp[i] + wt[i];
+    fk_quat_mul(lr, jq, tmp);
+    fk_quat_mul(pr, tmp, cr);
+    {
+      const int jj = PARTS == 1 ? j : j % hb;
+#pragma unroll
+      for (int i = 0; i < 3; i++) img[lane * prow + 3 * jj + i] = cp[i];
+    }
+    const int sv = fk_const(t.save_slot, j);
+    if (sv >= 0) {
+      float *s = slots + (size_t)sv * 7 * kFkWave + lane;
+#pragma unroll
+      for (int i = 0; i < 3; i++) s[i * kFkWave] = cp[i];
+#pragma unroll
+      for (int i = 0; i < 4; i++) s[(3 + i) * kFkWave] = cr[i];
+    }
+  }
+  {
+    const int j0 = PARTS == 1 ? 0 : (nbody - 1) / hb * hb;
+    flush_part(j0, nbody - j0);
   }
 }
 

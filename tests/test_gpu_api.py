@@ -529,7 +529,7 @@ def test_bench_two_rank_path_rehearsal():
     assert c["rccl_ranks"] == 2 and c["allgather_complete"] and c["allgather_qpos_ms"] > 0 and c["allgather_bytes_per_rank"] == 64 * 60 * 36 * 8
     assert d["strong"]["clips_total"] == 64 and d["strong"]["value"] > 0
     lc = d["long_clips_sharded"]
-    assert lc["ranks"] == 2 and lc["clips"] == 77 and lc["frames_per_s"] > 0 and lc["resolved_frames"] < 0.05 * lc["frames"]
+    assert lc["ranks"] == 2 and lc["clips"] == 77 and lc["frames_per_s"] > 0 and lc["resolved_frames"] < 0.05 * lc["frames"]  # (initial headings within 1 rad: speculative starts hit the right basin)
 
 
 def test_caller_access_pattern_of_fbx_to_robot():
