@@ -746,6 +746,15 @@ int build_device_model(gmr_model *m) {
   const size_t o_parent = P.add(v_parent);
   const size_t o_dofidx = P.add(dofidx), o_src = P.add(src_slot), o_save = P.add(save_slot);
   const size_t o_lpos = P.add(lpos), o_lrot = P.add(lrot), o_jaxis = P.add(jaxis), o_jaxis64 = P.add(jaxis64);
+  std::vector<gmr::FkBody> fkbody(nb);
+  for (int b = 0; b < nb; ++b) {
+    gmr::FkBody &r = fkbody[b];
+    r = gmr::FkBody{};
+    r.src_slot = src_slot[b]; r.dofidx = dofidx[b]; r.save_slot = save_slot[b];
+    for (int i = 0; i < 3; ++i) { r.lpos[i] = lpos[3 * b + i]; r.axis[i] = jaxis64[3 * b + i]; }
+    for (int i = 0; i < 4; ++i) r.lrot[i] = lrot[4 * b + i];
+  }
+  const size_t o_fkbody = P.add(fkbody);
 
   HIP_TRY(m, hipMalloc(&m->dev, P.buf.size()));
   m->dev_bytes = P.buf.size();
@@ -755,7 +764,7 @@ int build_device_model(gmr_model *m) {
   m->dm_eval_dev = DP(gmr::DevModel, o_dm_eval);
   gmr::FkTree &fk = m->fk;
   fk.parent = DP(int, o_parent); fk.dofidx = DP(int, o_dofidx); fk.src_slot = DP(int, o_src); fk.save_slot = DP(int, o_save);
-  fk.lpos = DP(float, o_lpos); fk.lrot = DP(float, o_lrot); fk.jaxis = DP(float, o_jaxis); fk.jaxis64 = DP(double, o_jaxis64);
+  fk.lpos = DP(float, o_lpos); fk.lrot = DP(float, o_lrot); fk.jaxis = DP(float, o_jaxis); fk.jaxis64 = DP(double, o_jaxis64); fk.body = DP(gmr::FkBody, o_fkbody);
   fk.nbody = nb; fk.ndof = nq - 7; fk.nslots = nslots;
   fk.dof_in_order = 1;
   for (int b = 0, prev = -1; b < nb; ++b)

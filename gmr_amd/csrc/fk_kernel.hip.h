@@ -37,12 +37,23 @@ constexpr int kFkPosStride = 3 * kFkGroup + 1;    // LDS words per lane of the p
 constexpr int kFkRotStride = 4 * kFkGroup + 1;
 constexpr int kFkMaxSlots = 12;
 
+// Everything the chain needs about one body, in one 80-byte record: read with two scalar loads (s_load_dwordx16 + x4) and
+// fetched one body ahead of its use, instead of a dozen dependent scalar loads per body in front of the wave-uniform branches.
+struct FkBody {
+  int src_slot, dofidx, save_slot, pad0;  // src_slot: -1 = the previous body is the parent; dofidx: -1 = no hinge
+  float lpos[3], pad1;                    // local translation
+  float lrot[4];                          // local rotation xyzw, raw XML values (not normalised)
+  double axis[3], pad2;                   // unit hinge axis in float64 (torch promotes the hinge quaternion to float64)
+};
+static_assert(sizeof(FkBody) == 80, "FkBody layout");
+
 struct FkTree {     // device arrays, [nbody]
   const int *parent, *dofidx, *src_slot, *save_slot;  // dofidx: -1 if no hinge; src_slot: -1 = previous body
   const float *lpos;   // [nb][3] local translation
   const float *lrot;   // [nb][4] local rotation xyzw, raw XML values (not normalised)
   const float *jaxis;  // [nb][3] hinge axis, unit (double normalised, then rounded)
   const double *jaxis64;  // [nb][3] unit axis in float64 (torch promotes the hinge quaternion to float64)
+  const FkBody *body;     // [nb] the same, one record per body (what the kernels read)
   int nbody, ndof, nslots, dof_in_order;  // dof_in_order: dofidx never decreases along the bodies (the register window needs it)
 };
 
@@ -82,21 +93,41 @@ __device__ __forceinline__ T fk_const(const T *p, int i) {
 
 // axis_angle_to_quat (torch_utils.py:353-359 through kinematics_model.py:21-36): sin/cos in float32, the product with the
 // float64 axis and the renormalisation in float64, the result rounded to float32.
-__device__ __forceinline__ void fk_hinge_quat(const FkTree &t, int j, float ang, float jq[4]) {
+__device__ __forceinline__ void fk_hinge_quat(const double ax[3], float ang, float jq[4]) {
 #pragma clang fp contract(off)
   const float th = ang / 2.0f;
   float sf, cf;
   sincosf(th, &sf, &cf);  // one range reduction for both; same values as sinf / cosf
   const double s = (double)sf, c = (double)cf;
-  const double qx = fk_const(t.jaxis64, 3 * j) * s, qy = fk_const(t.jaxis64, 3 * j + 1) * s, qz = fk_const(t.jaxis64, 3 * j + 2) * s;
-  // / max(|q|, 1e-9) in float64: |q| = 1 to float32 rounding here (unit axis, sin^2 + cos^2), so the clamp never binds and
-  // a Newton-refined reciprocal square root (<= 1 ulp in float64, invisible after the cast to float32) replaces sqrt + 4 divides
+  const double qx = ax[0] * s, qy = ax[1] * s, qz = ax[2] * s;
+  // / max(|q|, 1e-9) in float64.  |q|^2 = 1 + e with |e| ~ 1e-7 (unit axis, float32 sin^2 + cos^2), so the clamp never binds
+  // and 1 / sqrt(1 + e) = 1 - e / 2 + 3 e^2 / 8 - ...: the first Newton step from 1, r = 1.5 - 0.5 |q|^2, is exact to
+  // 3 e^2 / 8 < 1e-13 -- far below the float32 rounding of the result.  Anything else takes the general path.
   const double n2 = qx * qx + qy * qy + qz * qz + c * c;
-  double r = __builtin_amdgcn_rsq(n2);
-  r = r * (1.5 - 0.5 * n2 * r * r);
-  r = r * (1.5 - 0.5 * n2 * r * r);
-  r = n2 < 1e-18 ? 1e9 : r;
+  double r = 1.5 - 0.5 * n2;
+  if (__builtin_expect(__any(fabs(n2 - 1.0) > 1e-5), 0)) {
+    double rr = __builtin_amdgcn_rsq(n2);
+    rr = rr * (1.5 - 0.5 * n2 * rr * rr);
+    rr = rr * (1.5 - 0.5 * n2 * rr * rr);
+    r = n2 < 1e-18 ? 1e9 : rr;
+  }
   jq[0] = (float)(qx * r); jq[1] = (float)(qy * r); jq[2] = (float)(qz * r); jq[3] = (float)(c * r);
+}
+
+// One body record through the constant address space (scalar loads).
+__device__ __forceinline__ FkBody fk_body(const FkTree &t, int j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const auto *p = reinterpret_cast<const FkBody __attribute__((address_space(4))) *>(reinterpret_cast<uintptr_t>(t.body)) + j;
+  FkBody r;
+  r.src_slot = p->src_slot; r.dofidx = p->dofidx; r.save_slot = p->save_slot; r.pad0 = 0; r.pad1 = 0.f; r.pad2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; i++) { r.lpos[i] = p->lpos[i]; r.axis[i] = p->axis[i]; }
+#pragma unroll
+  for (int i = 0; i < 4; i++) r.lrot[i] = p->lrot[i];
+  return r;
+#else
+  return t.body[j];
+#endif
 }
 
 template <int MODE>
@@ -170,10 +201,13 @@ __global__ void __launch_bounds__(kFkThreads) fk_kernel(FkTree t, const float *_
     }
   };
   if (MODE == 0) stage(0);
+  FkBody nxt = fk_body(t, nbody > 1 ? 1 : 0);
   for (int j = 1; j < nbody; ++j) {
+    const FkBody rec = nxt;
+    nxt = fk_body(t, j + 1 < nbody ? j + 1 : j);  // one body ahead
     if (MODE == 0 && (j % kFkGroup) == 0) flush_n(j - kFkGroup, std::integral_constant<int, kFkGroup>{});
     float pp[3], pr[4];
-    const int src = fk_const(t.src_slot, j);
+    const int src = rec.src_slot;
     if (src < 0) {
 #pragma unroll
       for (int i = 0; i < 3; i++) pp[i] = cp[i];
@@ -187,7 +221,7 @@ __global__ void __launch_bounds__(kFkThreads) fk_kernel(FkTree t, const float *_
       for (int i = 0; i < 4; i++) pr[i] = s[(3 + i) * kFkThreads];
     }
     float jq[4] = {0.f, 0.f, 0.f, 1.f};
-    const int di = fk_const(t.dofidx, j);
+    const int di = rec.dofidx;
     if (di >= 0) {
       float ang;
       if (windowed) {  // (all conditions wave-uniform: the tree is)
@@ -204,10 +238,10 @@ __global__ void __launch_bounds__(kFkThreads) fk_kernel(FkTree t, const float *_
       } else {
         ang = myrow[di];
       }
-      fk_hinge_quat(t, j, ang, jq);
+      fk_hinge_quat(rec.axis, ang, jq);
     }
-    const float lt[3] = {fk_const(t.lpos, 3 * j), fk_const(t.lpos, 3 * j + 1), fk_const(t.lpos, 3 * j + 2)};
-    const float lr[4] = {fk_const(t.lrot, 4 * j), fk_const(t.lrot, 4 * j + 1), fk_const(t.lrot, 4 * j + 2), fk_const(t.lrot, 4 * j + 3)};
+    const float lt[3] = {rec.lpos[0], rec.lpos[1], rec.lpos[2]};
+    const float lr[4] = {rec.lrot[0], rec.lrot[1], rec.lrot[2], rec.lrot[3]};
     float wt[3], tmp[4];
     fk_quat_rotate(pr, lt, wt);
 #pragma unroll
@@ -216,7 +250,7 @@ __global__ void __launch_bounds__(kFkThreads) fk_kernel(FkTree t, const float *_
     fk_quat_mul(pr, tmp, cr);
     if (MODE == 0) stage(j % kFkGroup);
     else zmin = fminf(zmin, cp[2]);
-    const int sv = fk_const(t.save_slot, j);
+    const int sv = rec.save_slot;
     if (sv >= 0) {
       float *s = slots + (size_t)sv * 7 * kFkThreads + tid;
 #pragma unroll
@@ -315,10 +349,13 @@ __global__ void __launch_bounds__(kFkWave) fk_pos_kernel(FkTree t, const float *
   };
 #pragma unroll
   for (int i = 0; i < 3; i++) img[lane * prow + i] = cp[i];
+  FkBody nxt = fk_body(t, nbody > 1 ? 1 : 0);
   for (int j = 1; j < nbody; ++j) {
+    const FkBody rec = nxt;
+    nxt = fk_body(t, j + 1 < nbody ? j + 1 : j);  // one body ahead
     if (PARTS > 1 && j % hb == 0) flush_part(j - hb, hb);
     float pp[3], pr[4];
-    const int src = fk_const(t.src_slot, j);
+    const int src = rec.src_slot;
     if (src < 0) {
 #pragma unroll
       for (int i = 0; i < 3; i++) pp[i] = cp[i];
@@ -332,7 +369,7 @@ __global__ void __launch_bounds__(kFkWave) fk_pos_kernel(FkTree t, const float *
       for (int i = 0; i < 4; i++) pr[i] = s[(3 + i) * kFkWave];
     }
     float jq[4] = {0.f, 0.f, 0.f, 1.f};
-    const int di = fk_const(t.dofidx, j);
+    const int di = rec.dofidx;
     if (di >= 0) {
       float ang;
       if (windowed) {
@@ -349,10 +386,10 @@ __global__ void __launch_bounds__(kFkWave) fk_pos_kernel(FkTree t, const float *
       } else {
         ang = myrow[di];
       }
-      fk_hinge_quat(t, j, ang, jq);
+      fk_hinge_quat(rec.axis, ang, jq);
     }
-    const float lt[3] = {fk_const(t.lpos, 3 * j), fk_const(t.lpos, 3 * j + 1), fk_const(t.lpos, 3 * j + 2)};
-    const float lr[4] = {fk_const(t.lrot, 4 * j), fk_const(t.lrot, 4 * j + 1), fk_const(t.lrot, 4 * j + 2), fk_const(t.lrot, 4 * j + 3)};
+    const float lt[3] = {rec.lpos[0], rec.lpos[1], rec.lpos[2]};
+    const float lr[4] = {rec.lrot[0], rec.lrot[1], rec.lrot[2], rec.lrot[3]};
     float wt[3], tmp[4];
     fk_quat_rotate(pr, lt, wt);
 #pragma unroll
@@ -364,7 +401,7 @@ __global__ void __launch_bounds__(kFkWave) fk_pos_kernel(FkTree t, const float *
 #pragma unroll
       for (int i = 0; i < 3; i++) img[lane * prow + 3 * jj + i] = cp[i];
     }
-    const int sv = fk_const(t.save_slot, j);
+    const int sv = rec.save_slot;
     if (sv >= 0) {
       float *s = slots + (size_t)sv * 7 * kFkWave + lane;
 #pragma unroll
