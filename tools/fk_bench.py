@@ -19,11 +19,14 @@ root = torch.randn(N, 3, device=dev, generator=g)
 rot = torch.nn.functional.normalize(torch.randn(N, 4, device=dev, generator=g), dim=1)
 dof = 0.5 * torch.randn(N, nd, device=dev, generator=g)
 out = {}
+only = os.environ.get("FK_BENCH_ONLY")
 for name, fn, bytes_per in (
     ("fk_pos", lambda: eng.fk(root, rot, dof, want_rot=False), (7 + nd) * 4 + eng.nbody * 12),
     ("fk_pos_rot", lambda: eng.fk(root, rot, dof, want_rot=True), (7 + nd) * 4 + eng.nbody * 28),
     ("fk_min_height", lambda: eng.fk_min_height(root, rot, dof, np.arange(0, N + 1, 4000)), (7 + nd) * 4),
 ):
+    if only and name != only:
+        continue
     fn(); torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
