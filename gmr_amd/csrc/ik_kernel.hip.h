@@ -1067,6 +1067,17 @@ __device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool 
   return it < kMaxIt ? it : -it;
 }
 
+// The launch arguments, re-read from the kernarg segment where they are used (a scalar load per use, once per frame or per
+// solve) instead of living in SGPRs for the whole work item: by-value kernel arguments are loaded once in the prologue, and
+// the ~40 SGPRs they occupy across the QP were a third of this kernel's SGPR spills.  The pointer is opaque to the optimiser,
+// so the loads stay where they are written.  (IkLaunch is the second kernel argument: offset 8 behind the model pointer.)
+using IkLaunchK = const IkLaunch __attribute__((address_space(4)));
+__device__ __forceinline__ IkLaunchK *ik_launch_args() {
+  auto p = (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + 8;
+  asm volatile("" : "+s"(p));
+  return (IkLaunchK *)p;
+}
+
 // ------------------------------------------------------------------ the kernel
 template <int NVP, bool SQ>
 __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const DevModel *__restrict__ mp, IkLaunch L, LdsLayout lay) {
@@ -1104,7 +1115,6 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
       fkj.act[r] = __ballot(a != 0xff);
     }
   }
-  const gmr_ik_params prm = L.prm;
 #ifdef GMR_IK_STAMPS
   u64 stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   u64 stamp_last = __builtin_readcyclecounter();
@@ -1145,12 +1155,12 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
   int out_done = 0, kc = 0, left = 0;
   for (int kf = 0; kf < nfr; ++kf) {
     if (w.check_stride > 0 && left == 0) {
-      double *B = L.qfinal + (size_t)(w.burn_row + kc) * nq;
+      double *B = ik_launch_args()->qfinal + (size_t)(w.burn_row + kc) * nq;
       double d = 0.0;
       for (int i = lane; i < nq; i += 64) d = fmax(d, fabs(q[i] - B[i]));
       const int len = min(w.check_stride, nfr - kf);
-      if (wave_max(d) < prm.check_tol) {  // wave-uniform
-        const double *Fk = L.qfinal + (size_t)(w.final_row + kc) * nq;
+      if (wave_max(d) < ik_launch_args()->prm.check_tol) {  // wave-uniform
+        const double *Fk = ik_launch_args()->qfinal + (size_t)(w.final_row + kc) * nq;
         __syncthreads();
         for (int i = lane; i < nq; i += 64) q[i] = Fk[i];
         __syncthreads();
@@ -1163,15 +1173,19 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
       left = len;
     }
     const int64_t f = w.frame_begin + kf;
-    if (w.check_stride == 0 && kf == w.n_burn && w.burn_row >= 0 && L.qfinal)  // state the first output frame starts from
-      for (int i = lane; i < nq; i += 64) L.qfinal[(size_t)w.burn_row * nq + i] = q[i];
+    if (w.check_stride == 0 && kf == w.n_burn && w.burn_row >= 0) {  // state the first output frame starts from
+      double *qfin = ik_launch_args()->qfinal;
+      if (qfin)
+        for (int i = lane; i < nq; i += 64) qfin[(size_t)w.burn_row * nq + i] = q[i];
+    }
     GMR_STAMP(10);
     // ---- target preparation (update_targets: scale_human_data + offset_human_data, table-1 offsets) ----
     {
       double hp[3] = {0, 0, 0}, hq[4] = {1, 0, 0, 0}, rp[3];
-      const int64_t base = f * L.n_cols;
-      if (L.in_f64) {
-        const double *P = (const double *)L.hpos, *Q = (const double *)L.hquat;
+      IkLaunchK *La = ik_launch_args();
+      const int64_t base = f * La->n_cols;
+      if (La->in_f64) {
+        const double *P = (const double *)La->hpos, *Q = (const double *)La->hquat;
 #pragma unroll
         for (int i = 0; i < 3; i++) rp[i] = P[(base + root_col) * 3 + i];
         if (is_slot) {
@@ -1181,7 +1195,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
           for (int i = 0; i < 4; i++) hq[i] = Q[(base + s_col) * 4 + i];
         }
       } else {
-        const float *P = (const float *)L.hpos, *Q = (const float *)L.hquat;
+        const float *P = (const float *)La->hpos, *Q = (const float *)La->hquat;
 #pragma unroll
         for (int i = 0; i < 3; i++) rp[i] = (double)P[(base + root_col) * 3 + i];
         if (is_slot) {
@@ -1209,7 +1223,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         for (int i = 0; i < 3; i++) p[i] += g[i];
         if (m.sfoot[lane]) pz = p[2];
       }
-      if (prm.offset_to_ground) {
+      if (La->prm.offset_to_ground) {
         const double lowest = wave_min(pz);
         p[2] = p[2] - lowest + 0.1;
       }
@@ -1292,7 +1306,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
           if (quad) task_block_quad(ts, e, jl_kap, jl_bet, t_rs, t_xb, t_wp, t_wr, Bt + kBT * tl);
           else task_block(t_body, xpos, xquat, e, jl_kap, jl_bet, t_wp, t_wr, Bt + kBT * tl);
         }
-        const double diag = prm.damping + prm.lm_damping * sum_mu;
+        const double diag = ik_launch_args()->prm.damping + ik_launch_args()->prm.lm_damping * sum_mu;
         GMR_STAMP(3);
         // ---- screws S_i (world frame, about the origin) ----
         double Si[6] = {0, 0, 0, 0, 0, 0};
@@ -1368,8 +1382,9 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
           if (!SQ && a_lim) {  // mink ConfigurationLimit: -gain (q - lower) <= dq <= gain (upper - q)
             const double qv = q[a_qadr];
             const int ar = launder(2 * lane);
-            lo = -prm.limit_gain * (qv - m.arange[ar]);
-            hi = prm.limit_gain * (m.arange[ar + 1] - qv);
+            const double lgain = ik_launch_args()->prm.limit_gain;
+            lo = -lgain * (qv - m.arange[ar]);
+            hi = lgain * (m.arange[ar + 1] - qv);
           }
         }
         __syncthreads();  // Bc / poses are dead from here: H overwrites them
@@ -1427,7 +1442,8 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
           const double s_ci = sq_own ? c_in : 0.0;
           // mink ConfigurationLimit, evaluated by the lane that owns the dof in the QP layout: -gain (q - lower) <= dq <= gain (upper - q)
           const double qv = q[sq_qadr];
-          const double s_lo = fmax(-prm.limit_gain * (qv - sq_rlo), -1e30), s_hi = fmin(prm.limit_gain * (sq_rhi - qv), 1e30);
+          const double lgain = ik_launch_args()->prm.limit_gain;
+          const double s_lo = fmax(-lgain * (qv - sq_rlo), -1e30), s_hi = fmin(lgain * (sq_rhi - qv), 1e30);
           double xs;
 #ifdef GMR_DUP_PHASE
           if (GMR_DUP_PHASE == 8) { int st2 = sq_status; double x2; (void)box_qp_struct(lane, m.sq_nlimb, sq_own, sq_pad, Hm, s_ci, s_lo, s_hi, st2, x2); asm volatile("" :: "v"(x2)); }
@@ -1475,16 +1491,19 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         GMR_STAMP(2);
         if (!first) ++num_iter;
         first = false;
-        if (!(curr - next > prm.tol && num_iter < prm.max_iter)) break;
+        if (!(curr - next > ik_launch_args()->prm.tol && num_iter < ik_launch_args()->prm.max_iter)) break;
         curr = next;
       }
     }
     if (kf >= w.n_burn) {
-      for (int i = lane; i < nq; i += 64) L.qout[(size_t)f * nq + i] = q[i];
-      if (L.iters && lane == 0) L.iters[f] = solves | (qpflag << 30);
+      IkLaunchK *Lo = ik_launch_args();
+      double *qout = Lo->qout;
+      int *itp = Lo->iters;
+      for (int i = lane; i < nq; i += 64) qout[(size_t)f * nq + i] = q[i];
+      if (itp && lane == 0) itp[f] = solves | (qpflag << 30);
       ++out_done;
       if (w.check_stride > 0 && --left == 0) {  // a chunk solved here: its final state
-        double *Fk = L.qfinal + (size_t)(w.final_row + kc) * nq;
+        double *Fk = ik_launch_args()->qfinal + (size_t)(w.final_row + kc) * nq;
         for (int i = lane; i < nq; i += 64) Fk[i] = q[i];
         ++kc;
       }

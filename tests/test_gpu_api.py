@@ -609,3 +609,33 @@ def test_one_handle_on_two_streams():
     for k in (0, 1):
         q_ref, it_ref, _ = orc.ik_solve(sets[k][4], sets[k][5], sets[k][2], sets[k][3], n_threads=8)
         assert np.abs(outs[k][0].cpu().numpy() - q_ref).max() < 1e-6 and np.array_equal(outs[k][1].cpu().numpy(), it_ref)
+
+
+def test_host_pipeline_bitwise_equals_resident_path():
+    """Engine.ik_solve_host (host arrays in, pinned host result out, batches alternating between two streams) against ik_solve on
+    resident tensors: same kernel, same per-clip work items -> bitwise equal, whatever the batch split; with the 55-column SMPL-X
+    layout (slot_col picks 14 columns on the device) and per-clip heights.  retarget_batch routes big numpy batches through it."""
+    from gmr_amd import GeneralMotionRetargeting as GMR
+    from gmr_amd.engine import Engine
+    cm = compiled("smplx", "unitree_g1")
+    eng = Engine(cm, 0)
+    lens = [40, 7, 63, 21, 35, 12, 50, 9, 28]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    pos, quat, names, _, _ = synth.synth_clips(cm, 1, int(offs[-1]), seed=17, hard=True, dtype=np.float32, pad_to=55)
+    perm = np.random.default_rng(0).permutation(55)                        # the used columns anywhere among the 55
+    pos, quat, names = np.ascontiguousarray(pos[:, perm]), np.ascontiguousarray(quat[:, perm]), [names[i] for i in perm]
+    sc = cm.slot_columns(names)
+    hs = np.linspace(0.9, 1.1, len(lens))
+    items = make_items(offs, height_scales=hs)
+    q_res, it_res, _ = eng.ik_solve(torch.from_numpy(pos).cuda(), torch.from_numpy(quat).cuda(), sc, items)
+    for min_clips, max_b in ((1, 4), (2, 3), (1000, 4)):                     # 4 batches, 3 batches, one batch
+        q, it = eng.ik_solve_host(pos, quat, sc, offs, height_scales=hs, min_batch_clips=min_clips, max_batches=max_b)
+        assert np.array_equal(q, q_res.cpu().numpy()) and np.array_equal(it, it_res.cpu().numpy())
+    g = GMR("smplx", "unitree_g1")
+    g.HOST_PIPELINE_MIN_FRAMES = 1
+    q2 = g.retarget_batch(pos, quat, names, seq_offsets=offs, human_heights=hs * cm.config.human_height_assumption)
+    assert isinstance(q2, np.ndarray) and np.array_equal(q2, q_res.cpu().numpy())
+    bad = pos.copy()
+    bad[5, sc[3]] = np.nan
+    with pytest.raises(FloatingPointError):
+        eng.ik_solve_host(bad, quat, sc, offs)
