@@ -340,7 +340,7 @@ def main():
                                                        out_pos=bp_out[: nf // 2], out_rot=br_out), 3, 1)
         fk_bytes2 = fk_bytes + eng.nbody * 16
         result["fk"] = {
-            "kernel": "gmr::fk_kernel<0>", "frames": nf, "kernel_ms": fk_ms, "frames_per_s": nf / (fk_ms * 1e-3),
+            "kernel": "gmr::fk_pos_kernel<1> (positions; gmr::fk_kernel<0> with rotations)", "frames": nf, "kernel_ms": fk_ms, "frames_per_s": nf / (fk_ms * 1e-3),
             "roofline": {"bound": "hbm", "achieved": fk_bytes * nf / (fk_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": fk_bytes * nf / (fk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_frame": fk_bytes, "traffic": None},
             "with_rotations": {"frames": nf // 2, "kernel_ms": fk_ms2, "bytes_per_frame": fk_bytes2,
@@ -422,8 +422,9 @@ def main():
         t_ser, _ = timed(serial, reps=2)
         result["host_fed"] = {"frames": nh, "frames_per_s": nh / t_host, "bitwise_equal_to_resident": same,
                               "serial_pageable_frames_per_s": (nh // 4) / t_ser,
-                              "includes": "pageable host key-points -> pinned staging -> H2D (392 B/frame) + kernel + D2H of qpos (288 B/frame) into a pinned "
-                                          "host result, two streams; serial_pageable = round 1's copy-in / solve / copy-out without overlap"}
+                              "includes": "pageable host key-points read in place by the copy engine (H2D 392 B/frame) + kernel + D2H of qpos (288 B/frame) into a "
+                                          "pinned host result, batches of >= 2048 clips alternating between two streams; serial_pageable = round 1's "
+                                          "copy-in / solve / copy-out into a fresh pageable array, no overlap (a quarter of the frames)"}
         del hp_all, hq_all, q_host
     if rank == 0 and world == 1 and not args.no_cpu and not args.hot_only:
         from oracle.oracle import Oracle  # checker / comparator only
