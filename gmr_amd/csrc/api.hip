@@ -263,19 +263,6 @@ int build_device_model(gmr_model *m) {
         if (b >= a) { set_err(m, "internal: elimination order breaks ancestor-first indexing"); return GMR_EINVAL; }
         aanc[a] |= 1ull << b;
       }
-  // batches of mutually independent pivots (<= 4 consecutive indices of one height; padding rows are independent of
-  // everything): bit p of qp_top marks the highest index of a batch.
-  u64 qp_top = 0;
-  {
-    auto group = [&](int p) { return p >= n_act ? -1 : height[p]; };
-    int p = nvp - 1;
-    while (p >= 0) {
-      qp_top |= 1ull << p;
-      int w = 1;
-      while (w < 4 && p - w >= 0 && group(p - w) == group(p)) ++w;
-      p -= w;
-    }
-  }
   // ---- FK pointer-jumping plan: ancestor folded in each round, one byte per round (for the pruned IK tree and the full tree) ----
   auto fk_plan = [&](const std::vector<int> &par, std::vector<u64> &plan, int &rounds) -> bool {
     const int n = (int)par.size();
