@@ -26,7 +26,8 @@ INIT_QPOS0, INIT_ROOT_TARGET = -1, -2
 
 EXPORTS = ["gmr_abi_version", "gmr_model_create", "gmr_model_destroy", "gmr_last_error", "gmr_model_info_get",
            "gmr_ik_solve", "gmr_fk", "gmr_fk_min_height", "gmr_bvh_fk", "gmr_bvh_parse_header", "gmr_bvh_parse_motion", "gmr_evaluate", "gmr_smplx_keypoints",
-           "gmr_session_create", "gmr_session_destroy", "gmr_session_reset", "gmr_session_step", "gmr_session_state"]
+           "gmr_session_create", "gmr_session_destroy", "gmr_session_reset", "gmr_session_step", "gmr_session_state",
+           "gmr_group_create", "gmr_group_destroy", "gmr_group_size", "gmr_group_model", "gmr_group_last_error", "gmr_group_ik_solve"]
 
 
 class IKParams(C.Structure):
@@ -47,6 +48,16 @@ class ModelInfo(C.Structure):
         ("nbody", C.c_int32), ("nq", C.c_int32), ("nv", C.c_int32), ("nslot", C.c_int32), ("ntask", C.c_int32 * 2),
         ("n_active_dof", C.c_int32), ("nv_padded", C.c_int32), ("lds_bytes", C.c_int32), ("device", C.c_int32),
         ("reserved", C.c_int32 * 6),
+    ]
+
+
+class GroupInput(C.Structure):
+    """``gmr_group_input`` (include/gmr_amd.h): one member's arguments of a group launch."""
+
+    _fields_ = [
+        ("human_pos", C.c_void_p), ("human_quat", C.c_void_p), ("in_dtype", C.c_int32), ("n_cols", C.c_int32),
+        ("slot_col", C.c_void_p), ("n_frames", C.c_int64), ("items", C.c_void_p), ("n_items", C.c_int32), ("reserved", C.c_int32),
+        ("qpos_init", C.c_void_p), ("qpos_final", C.c_void_p), ("qpos_out", C.c_void_p), ("iters_out", C.c_void_p), ("frames_done", C.c_void_p),
     ]
 
 
@@ -91,6 +102,17 @@ def load():
     L.gmr_fk.argtypes = [vp, vp, vp, vp, C.c_int64, vp, vp, vp]
     L.gmr_fk_min_height.restype = C.c_int
     L.gmr_fk_min_height.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp]
+    L.gmr_group_create.restype = vp
+    L.gmr_group_create.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+    L.gmr_group_destroy.argtypes = [vp]
+    L.gmr_group_size.restype = C.c_int
+    L.gmr_group_size.argtypes = [vp]
+    L.gmr_group_model.restype = vp
+    L.gmr_group_model.argtypes = [vp, C.c_int]
+    L.gmr_group_last_error.restype = C.c_char_p
+    L.gmr_group_last_error.argtypes = [vp]
+    L.gmr_group_ik_solve.restype = C.c_int
+    L.gmr_group_ik_solve.argtypes = [vp, C.POINTER(GroupInput), C.POINTER(IKParams), vp]
     L.gmr_bvh_parse_header.restype = C.c_int
     L.gmr_bvh_parse_header.argtypes = [C.c_char_p, C.c_size_t, C.c_int, vp, C.c_size_t, vp, vp, vp, vp, vp, vp, vp]
     L.gmr_evaluate.restype = C.c_int

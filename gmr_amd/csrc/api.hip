@@ -42,6 +42,7 @@ struct gmr_model {
   gmr::LdsLayout lay{};
   int nvp = 0, n_act = 0, lds_bytes = 0, fk_lds_bytes = 0, fk_lds_bytes_min = 0;  // _min: the min-height mode has no output stage
   unsigned long long *dbg = nullptr;  // diagnostic builds (GMR_IK_STAMPS) only
+  int min_nvp = 0;                    // group members are built for a common kernel variant (gmr_group_create)
   int fk_pos_parts = 1;               // gmr_fk without rotations: fk_pos_kernel<parts> (GMR_AMD_FK_PARTS=0 falls back to fk_kernel<0>)
   bool force_generic = false;         // GMR_AMD_GENERIC_QP=1: use the dense generic QP even where the structured one applies
 };
@@ -55,6 +56,15 @@ struct gmr_session {
   size_t pos_bytes = 0, quat_bytes = 0, quat_off = 0, out_off = 0;
   gmr::IkLaunch L{};
 };
+
+// Several models built for one kernel variant (gmr_group_*).
+struct gmr_group {
+  std::vector<gmr_model *> models;
+  int device = -1, nvp = 0;
+  bool sq = false;
+  std::string err;
+};
+
 
 namespace {
 
@@ -148,6 +158,17 @@ int launch_ik_variant(gmr_model *m, const gmr::IkLaunch &L, hipStream_t st) {
   return GMR_OK;
 }
 
+template <int NVP>
+void launch_ik_group(const gmr_group *g, const gmr::IkGroupEntry *entries, const int *block_entry, int n_blocks, int lds_bytes, hipStream_t st) {
+  if (g->sq)
+    hipLaunchKernelGGL((gmr::ik_group_kernel<NVP, true>), dim3(n_blocks), dim3(64), lds_bytes, st, entries, block_entry);
+#ifndef GMR_IK_DEV_ONLY36
+  else
+    hipLaunchKernelGGL((gmr::ik_group_kernel<NVP, false>), dim3(n_blocks), dim3(64), lds_bytes, st, entries, block_entry);
+#endif
+}
+
+
 int build_device_model(gmr_model *m) {
   const gmr_blob_header &h = m->h;
   const auto &B = m->blob;
@@ -222,7 +243,7 @@ int build_device_model(gmr_model *m) {
     arange.push_back(range[2 * b]); arange.push_back(range[2 * b + 1]);
   }
   const int n_act = (int)abody.size();
-  const int nvp = pick_nvp(n_act);
+  const int nvp = pick_nvp(std::max(n_act, m->min_nvp));
   if (nvp < 0) { set_err(m, "%d active dofs exceed the kernel limit of 64", n_act); return GMR_EUNSUPPORTED; }
   // ancestor relation among active dofs in depth-first order (j above i implies j < i)
   auto dfs_anc = [&](int j, int i) {
@@ -785,7 +806,7 @@ extern "C" {
 
 int gmr_abi_version(void) { return GMR_ABI_VERSION; }
 
-gmr_model *gmr_model_create(const void *blob, size_t blob_bytes, int device, char *err, size_t err_len) {
+static gmr_model *model_create_impl(const void *blob, size_t blob_bytes, int device, int min_nvp, int force_generic, char *err, size_t err_len) {
   auto fail = [&](gmr_model *m, const char *msg) -> gmr_model * {
     if (err && err_len) snprintf(err, err_len, "%s", m && !m->err.empty() ? m->err.c_str() : msg);
     if (m) gmr_model_destroy(m);
@@ -827,9 +848,15 @@ gmr_model *gmr_model_create(const void *blob, size_t blob_bytes, int device, cha
       return fail(m, "stream-ordered memory pool unavailable on this device");
   }
   if (const char *e = getenv("GMR_AMD_GENERIC_QP")) m->force_generic = e[0] == '1';
+  if (force_generic) m->force_generic = true;
+  m->min_nvp = min_nvp;
   if (const char *e = getenv("GMR_AMD_FK_PARTS")) m->fk_pos_parts = e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1;
   if (build_device_model(m) != GMR_OK) return fail(m, "model build failed");
   return m;
+}
+
+gmr_model *gmr_model_create(const void *blob, size_t blob_bytes, int device, char *err, size_t err_len) {
+  return model_create_impl(blob, blob_bytes, device, 0, 0, err, err_len);
 }
 
 void gmr_model_destroy(gmr_model *m) {
@@ -852,11 +879,12 @@ int gmr_model_info_get(const gmr_model *m, gmr_model_info *out) {
   return GMR_OK;
 }
 
-int gmr_ik_solve(gmr_model *m, const void *human_pos, const void *human_quat, int in_dtype, int n_cols, const int32_t *slot_col,
-                 int64_t n_frames, const gmr_work_item *items, int n_items, const gmr_ik_params *params, const double *qpos_init,
-                 double *qpos_final, double *qpos_out, int32_t *iters_out, int32_t *frames_done, gmr_ik_stats *stats, void *stream) {
-  if (!m) return GMR_EINVAL;
-  m->err.clear();
+// Validate one model's batch, put its scheduling data (length-sorted work items, the caller's index of each, the slot columns)
+// into stream-ordered scratch and fill the launch arguments.  `order_host` receives the caller's index of every sorted item.
+static int prepare_ik_launch(gmr_model *m, const void *human_pos, const void *human_quat, int in_dtype, int n_cols, const int32_t *slot_col,
+                             int64_t n_frames, const gmr_work_item *items, int n_items, const gmr_ik_params *params,
+                             const double *qpos_init, double *qpos_final, double *qpos_out, int32_t *iters_out, int32_t *frames_done,
+                             gmr_ik_stats *stats, hipStream_t st, CallScratch &sc, gmr::IkLaunch &L, std::vector<gmr_work_item> &sorted) {
   if (m->h.nslot == 0 || (m->h.ntask[0] == 0 && m->h.ntask[1] == 0)) { set_err(m, "model has no IK config"); return GMR_ENOCONFIG; }
   if (!human_pos || !human_quat || !slot_col || !params || !qpos_out || (!items && n_items > 0)) { set_err(m, "null argument"); return GMR_EINVAL; }
   if (in_dtype != GMR_DTYPE_F32 && in_dtype != GMR_DTYPE_F64) { set_err(m, "in_dtype must be f32 or f64"); return GMR_EINVAL; }
@@ -886,20 +914,21 @@ int gmr_ik_solve(gmr_model *m, const void *human_pos, const void *human_quat, in
   if (need_init && !qpos_init) { set_err(m, "items reference qpos_init but it is NULL"); return GMR_EINVAL; }
   if (need_final && !qpos_final) { set_err(m, "items reference qpos_final but it is NULL"); return GMR_EINVAL; }
   if (stats) { memset(stats, 0, sizeof(*stats)); stats->n_items = n_items; stats->n_frames_total = tot; stats->n_frames_out = out; }
+  L = gmr::IkLaunch{};
+  L.n_items = n_items;
+  sorted.clear();
   if (n_items == 0) return GMR_OK;
 
   HIP_TRY(m, hipSetDevice(m->device));
-  hipStream_t st = static_cast<hipStream_t>(stream);
   // longest item first so that the tail of the grid is made of short ones
   std::vector<int> order(n_items);
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return items[a].n_burn + items[a].n_out > items[b].n_burn + items[b].n_out; });
-  std::vector<gmr_work_item> sorted(n_items);
+  sorted.resize(n_items);
   for (int i = 0; i < n_items; ++i) sorted[i] = items[order[i]];
   const size_t items_bytes = sizeof(gmr_work_item) * (size_t)n_items, col_bytes = sizeof(int32_t) * (size_t)m->h.nslot;
   const size_t order_off = (items_bytes + 15) & ~size_t(15), order_bytes = sizeof(int) * (size_t)n_items;
   const size_t col_off = (order_off + order_bytes + 15) & ~size_t(15);
-  CallScratch sc;
   int rc = scratch_alloc(m, sc, col_off + col_bytes, st);
   if (rc != GMR_OK) return rc;
   uint8_t *ws = static_cast<uint8_t *>(sc.p);
@@ -908,7 +937,6 @@ int gmr_ik_solve(gmr_model *m, const void *human_pos, const void *human_quat, in
   HIP_TRY(m, hipMemcpyAsync(ws + order_off, order.data(), order_bytes, hipMemcpyHostToDevice, st));
   HIP_TRY(m, hipMemcpyAsync(ws + col_off, slot_col, col_bytes, hipMemcpyHostToDevice, st));
 
-  gmr::IkLaunch L{};
   L.hpos = human_pos; L.hquat = human_quat; L.slot_col = reinterpret_cast<const int *>(ws + col_off);
   L.items = reinterpret_cast<const gmr_work_item *>(ws);
   L.order = reinterpret_cast<const int *>(ws + order_off); L.frames_done = frames_done;
@@ -918,7 +946,125 @@ int gmr_ik_solve(gmr_model *m, const void *human_pos, const void *human_quat, in
   if (!m->dbg) { HIP_TRY(m, hipMalloc(&m->dbg, 16 * sizeof(unsigned long long))); HIP_TRY(m, hipMemset(m->dbg, 0, 16 * sizeof(unsigned long long))); }
 #endif
   L.dbg = m->dbg;
+  return GMR_OK;
+}
+
+int gmr_ik_solve(gmr_model *m, const void *human_pos, const void *human_quat, int in_dtype, int n_cols, const int32_t *slot_col,
+                 int64_t n_frames, const gmr_work_item *items, int n_items, const gmr_ik_params *params, const double *qpos_init,
+                 double *qpos_final, double *qpos_out, int32_t *iters_out, int32_t *frames_done, gmr_ik_stats *stats, void *stream) {
+  if (!m) return GMR_EINVAL;
+  m->err.clear();
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  CallScratch sc;
+  gmr::IkLaunch L{};
+  std::vector<gmr_work_item> sorted;
+  int rc = prepare_ik_launch(m, human_pos, human_quat, in_dtype, n_cols, slot_col, n_frames, items, n_items, params, qpos_init, qpos_final,
+                             qpos_out, iters_out, frames_done, stats, st, sc, L, sorted);
+  if (rc != GMR_OK || n_items == 0) return rc;
   return launch_ik_variant(m, L, st);
+}
+
+// ------------------------------------------------------------------ several models in one launch (BASELINE config 4)
+gmr_group *gmr_group_create(const void *const *blobs, const size_t *blob_bytes, int n_models, int device, char *err, size_t err_len) {
+  auto fail = [&](gmr_group *g, const char *msg) -> gmr_group * {
+    if (err && err_len && msg) snprintf(err, err_len, "%s", msg);
+    if (g) gmr_group_destroy(g);
+    return nullptr;
+  };
+  if (!blobs || !blob_bytes || n_models < 1 || n_models > 64) return fail(nullptr, "a group holds 1 .. 64 models");
+  gmr_group *g = new gmr_group();
+  g->device = device;
+  // pass 1: every model as it would be built alone -> the common kernel variant; pass 2: rebuild the members that differ
+  int nvp = 0;
+  bool all_sq = true;
+  for (int i = 0; i < n_models; ++i) {
+    gmr_model *m = model_create_impl(blobs[i], blob_bytes[i], device, 0, 0, err, err_len);
+    if (!m) return fail(g, nullptr);
+    g->models.push_back(m);
+    if (m->h.nslot == 0 || (m->h.ntask[0] == 0 && m->h.ntask[1] == 0)) return fail(g, "every group member needs an IK config");
+    nvp = std::max(nvp, m->nvp);
+    all_sq = all_sq && m->dm.sq_ok && !m->force_generic;
+  }
+  for (int i = 0; i < n_models; ++i) {
+    gmr_model *m = g->models[i];
+    const bool sq = m->dm.sq_ok && !m->force_generic;
+    if (m->nvp == nvp && sq == all_sq) continue;
+    gmr_model_destroy(m);
+    g->models[i] = model_create_impl(blobs[i], blob_bytes[i], device, nvp, all_sq ? 0 : 1, err, err_len);
+    if (!g->models[i]) return fail(g, nullptr);
+    if (g->models[i]->nvp != nvp) return fail(g, "internal: group member did not take the common kernel variant");
+  }
+  g->nvp = nvp;
+  g->sq = all_sq;
+  return g;
+}
+
+void gmr_group_destroy(gmr_group *g) {
+  if (!g) return;
+  for (gmr_model *m : g->models) gmr_model_destroy(m);
+  delete g;
+}
+
+int gmr_group_size(const gmr_group *g) { return g ? (int)g->models.size() : 0; }
+gmr_model *gmr_group_model(gmr_group *g, int i) { return g && i >= 0 && i < (int)g->models.size() ? g->models[i] : nullptr; }
+const char *gmr_group_last_error(const gmr_group *g) { return g ? g->err.c_str() : "null group"; }
+
+int gmr_group_ik_solve(gmr_group *g, const gmr_group_input *inputs, const gmr_ik_params *params, void *stream) {
+  if (!g || !inputs || !params) return GMR_EINVAL;
+  g->err.clear();
+  const int n = (int)g->models.size();
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  std::vector<CallScratch> scratch(n);
+  std::vector<gmr::IkGroupEntry> entries(n);
+  std::vector<std::vector<gmr_work_item>> sorted(n);
+  int total = 0, lds_bytes = 0;
+  for (int i = 0; i < n; ++i) {
+    gmr_model *m = g->models[i];
+    m->err.clear();
+    const gmr_group_input &in = inputs[i];
+    gmr::IkLaunch L{};
+    int rc = prepare_ik_launch(m, in.human_pos, in.human_quat, in.in_dtype, in.n_cols, in.slot_col, in.n_frames, in.items, in.n_items, params,
+                               in.qpos_init, in.qpos_final, in.qpos_out, in.iters_out, in.frames_done, nullptr, st, scratch[i], L, sorted[i]);
+    if (rc != GMR_OK) { g->err = "member " + std::to_string(i) + ": " + m->err; return rc; }
+    entries[i].m = m->dm_dev; entries[i].L = L; entries[i].lay = m->lay; entries[i].item_base = 0; entries[i].pad = 0;
+    total += in.n_items;
+    if (in.n_items > 0) lds_bytes = std::max(lds_bytes, m->lds_bytes);
+  }
+  if (total == 0) return GMR_OK;
+  // one grid over all members' items: a block finds its entry in block_entry[] and its item as blockIdx - item_base, so the
+  // blocks of an entry are contiguous (its items longest first); the entry with the longest items goes first
+  std::vector<int> block_entry(total);
+  std::vector<int> eorder(n);
+  std::iota(eorder.begin(), eorder.end(), 0);
+  auto longest = [&](int e) { return sorted[e].empty() ? -1 : sorted[e][0].n_burn + sorted[e][0].n_out; };
+  std::stable_sort(eorder.begin(), eorder.end(), [&](int a, int b) { return longest(a) > longest(b); });
+  int blk = 0;
+  for (int e : eorder) {
+    entries[e].item_base = blk;
+    for (size_t k = 0; k < sorted[e].size(); ++k) block_entry[blk++] = e;
+  }
+  gmr_model *m0 = g->models[0];
+  if (hipSetDevice(g->device) != hipSuccess) { g->err = "hipSetDevice failed"; return GMR_EDEVICE; }
+  CallScratch gs;
+  const size_t ent_bytes = sizeof(gmr::IkGroupEntry) * (size_t)n, be_off = (ent_bytes + 15) & ~size_t(15);
+  int rc = scratch_alloc(m0, gs, be_off + sizeof(int) * (size_t)total, st);
+  if (rc != GMR_OK) { g->err = m0->err; return rc; }
+  uint8_t *ws = static_cast<uint8_t *>(gs.p);
+  if (hipMemcpyAsync(ws, entries.data(), ent_bytes, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(ws + be_off, block_entry.data(), sizeof(int) * (size_t)total, hipMemcpyHostToDevice, st) != hipSuccess) {
+    g->err = "hipMemcpyAsync failed";
+    return GMR_EDEVICE;
+  }
+  const auto *d_entries = reinterpret_cast<const gmr::IkGroupEntry *>(ws);
+  const int *d_be = reinterpret_cast<const int *>(ws + be_off);
+  switch (g->nvp) {
+#define GMR_X(v) case v: launch_ik_group<v>(g, d_entries, d_be, total, lds_bytes, st); break;
+    GMR_FOR_EACH_NVP(GMR_X)
+#undef GMR_X
+    default: g->err = "internal: no kernel variant"; return GMR_EUNSUPPORTED;
+  }
+  if (hipGetLastError() != hipSuccess) { g->err = "kernel launch failed"; return GMR_EDEVICE; }
+  return GMR_OK;
 }
 
 // ------------------------------------------------------------------ single-sequence sessions (teleop)

@@ -381,7 +381,16 @@ __device__ __forceinline__ void qrot(const double q[4], const double v[3], doubl
 }
 constexpr int kBodyC = 11;  // doubles per body in the LDS-staged joint tree: pos(3) quat(4) axis(3) {fkanc(6 bytes), jtype, qadr}
 // Stage this lane's body of the joint tree into LDS (once per wavefront).
-__device__ __forceinline__ void stage_tree(const DevModel &m, int lane, double *bodyc) {
+// The model is always read through the CONSTANT address space (it is read-only for every launch): a group launch gets its model
+// pointer from memory, and loads through a generic (flat) pointer count as divergent, loads through a global pointer that is not a
+// `restrict` kernel argument as clobberable -- either way every wave-uniform branch, mask and scalar constant derived from the
+// model would be a VMEM load into VGPRs instead of a scalar load.
+using DevModelG = const DevModel __attribute__((address_space(4)));
+// HIP's vector classes cannot be copied out of a qualified address space: read those members through a plain pointer (per-lane data).
+template <class T>
+__device__ __forceinline__ T ld_plain(const T __attribute__((address_space(4))) *p) { return *(const T *)(uintptr_t)p; }
+
+__device__ __forceinline__ void stage_tree(DevModelG &m, int lane, double *bodyc) {
   if (lane < m.nbody) {
     double *bcst = bodyc + kBodyC * lane;
 #pragma unroll
@@ -403,7 +412,7 @@ struct FkJump {
   u64 act[4];
 };
 template <bool STAGED, bool STEP = false, bool JUMP = false>
-__device__ __forceinline__ void fk_phase(const DevModel &m, const double *bodyc, int nbody, int nrounds, int lane, double *q,
+__device__ __forceinline__ void fk_phase(DevModelG &m, const double *bodyc, int nbody, int nrounds, int lane, double *q,
                                          double *xpos, double *xquat, double wx = 0.0, double wy = 0.0, double wz = 0.0,
                                          const FkJump *jp = nullptr) {
   const bool has = lane < nbody;
@@ -1067,21 +1076,20 @@ __device__ __forceinline__ int box_qp_struct(int lane, int nl, bool owner, bool 
   return it < kMaxIt ? it : -it;
 }
 
-// The launch arguments, re-read from the kernarg segment where they are used (a scalar load per use, once per frame or per
-// solve) instead of living in SGPRs for the whole work item: by-value kernel arguments are loaded once in the prologue, and
-// the ~40 SGPRs they occupy across the QP were a third of this kernel's SGPR spills.  The pointer is opaque to the optimiser,
-// so the loads stay where they are written.  (IkLaunch is the second kernel argument: offset 8 behind the model pointer.)
+// The launch arguments are re-read where they are used (a scalar load per use, once per frame or per solve) instead of living
+// in SGPRs for the whole work item: by-value kernel arguments are loaded once in the prologue, and the ~40 SGPRs they occupy
+// across the QP were a third of this kernel's SGPR spills.  The pointer is laundered (opaque to the optimiser) at every use,
+// so the loads stay where they are written.  It points into the kernarg segment (ik_kernel) or at the item's entry of a group
+// launch in device memory (ik_group_kernel); both are read-only for the launch, hence the constant address space.
 using IkLaunchK = const IkLaunch __attribute__((address_space(4)));
-__device__ __forceinline__ IkLaunchK *ik_launch_args() {
-  auto p = (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + 8;
+__device__ __forceinline__ IkLaunchK *ik_args(IkLaunchK *p) {
   asm volatile("" : "+s"(p));
-  return (IkLaunchK *)p;
+  return p;
 }
 
-// ------------------------------------------------------------------ the kernel
+// ------------------------------------------------------------------ the kernel body: one work item on one wavefront
 template <int NVP, bool SQ>
-__global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const DevModel *__restrict__ mp, IkLaunch L, LdsLayout lay) {
-  const DevModel &m = *mp;
+__device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLayout lay, const int item) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
   double *q = lds + lay.q, *xpos = lds + lay.xpos, *xquat = lds + lay.xquat, *tp = lds + lay.tp, *tq = lds + lay.tq;
@@ -1094,17 +1102,17 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
   {
     uint2 *hp = reinterpret_cast<uint2 *>(lds + lay.hplan);
     if (!(SQ && m.npairp <= 64 * kHPlanRegsSQ))  // (a plan that fits the registers has no LDS copy)
-      for (int i = lane; i < m.npairp; i += 64) hp[i] = m.hplan[i];
+      for (int i = lane; i < m.npairp; i += 64) hp[i] = ld_plain(&m.hplan[i]);
     uint4 *cp = reinterpret_cast<uint4 *>(lds + lay.cplan);
     const int n0 = 4 * m.ncpass[0], n1 = 4 * m.ncpass[1];
-    for (int i = lane; i < n0; i += 64) cp[i] = m.comp_plan[i];
-    for (int i = lane; i < n1; i += 64) cp[n0 + i] = m.comp_plan[4 * kMaxCompPass + i];
+    for (int i = lane; i < n0; i += 64) cp[i] = ld_plain(&m.comp_plan[i]);
+    for (int i = lane; i < n1; i += 64) cp[n0 + i] = ld_plain(&m.comp_plan[4 * kMaxCompPass + i]);
   }
-  const gmr_work_item w = L.items[blockIdx.x];
+  const gmr_work_item w = Lk->items[item];
   constexpr int kHPlanRegs = SQ ? kHPlanRegsSQ : 0, kCompRegs = SQ ? kCompRegsSQ : 0;
   uint2 hreg[kHPlanRegs > 0 ? kHPlanRegs : 1];  // this lane's entries of the first rounds of the H pair plan
 #pragma unroll
-  for (int r = 0; r < kHPlanRegs; ++r) hreg[r] = 64 * r < m.npairp ? m.hplan[64 * r + lane] : uint2{0, 0};
+  for (int r = 0; r < kHPlanRegs; ++r) hreg[r] = 64 * r < m.npairp ? ld_plain(&m.hplan[64 * r + lane]) : uint2{0, 0};
   FkJump fkj;  // (lane = body; bodies beyond the tree and finished chains fetch from themselves and do not fold)
   {
     const u64 an = lane < m.nbody ? m.fkanc[lane] : ~0ull;
@@ -1125,7 +1133,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
   const int arow = real_row ? lane : 0;
   const int a_body = m.abody[arow], a_kind = real_row ? m.akind[arow] : -1, a_qadr = m.aqadr[arow], a_lim = real_row ? m.alimited[arow] : 0;
   const bool is_slot = lane < nslot;
-  const int s_col = L.slot_col[is_slot ? lane : 0], root_col = L.slot_col[root_slot];
+  const int s_col = Lk->slot_col[is_slot ? lane : 0], root_col = Lk->slot_col[root_slot];
 
   // structured QP: this lane's row in the 4 x 16 layout
   const int sq_g = SQ ? (int)m.sq_gdof[lane] : -1;
@@ -1141,7 +1149,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
     if (m.alimited[sq_g]) { sq_rlo = m.arange[2 * sq_g]; sq_rhi = m.arange[2 * sq_g + 1]; }
   }
   int sq_status = 0;
-  for (int i = lane; i < nq; i += 64) q[i] = w.init_row >= 0 ? L.qinit[(size_t)w.init_row * nq + i] : m.qpos0[i];
+  for (int i = lane; i < nq; i += 64) q[i] = w.init_row >= 0 ? Lk->qinit[(size_t)w.init_row * nq + i] : m.qpos0[i];
   int status = real_row ? 0 : 3;
   __syncthreads();
   const double hscale = w.height_scale != 0.0 ? w.height_scale : 1.0;  // per-clip human height factor (gmr_blob.h)
@@ -1155,12 +1163,12 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
   int out_done = 0, kc = 0, left = 0;
   for (int kf = 0; kf < nfr; ++kf) {
     if (w.check_stride > 0 && left == 0) {
-      double *B = ik_launch_args()->qfinal + (size_t)(w.burn_row + kc) * nq;
+      double *B = ik_args(Lk)->qfinal + (size_t)(w.burn_row + kc) * nq;
       double d = 0.0;
       for (int i = lane; i < nq; i += 64) d = fmax(d, fabs(q[i] - B[i]));
       const int len = min(w.check_stride, nfr - kf);
-      if (wave_max(d) < ik_launch_args()->prm.check_tol) {  // wave-uniform
-        const double *Fk = ik_launch_args()->qfinal + (size_t)(w.final_row + kc) * nq;
+      if (wave_max(d) < ik_args(Lk)->prm.check_tol) {  // wave-uniform
+        const double *Fk = ik_args(Lk)->qfinal + (size_t)(w.final_row + kc) * nq;
         __syncthreads();
         for (int i = lane; i < nq; i += 64) q[i] = Fk[i];
         __syncthreads();
@@ -1174,7 +1182,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
     }
     const int64_t f = w.frame_begin + kf;
     if (w.check_stride == 0 && kf == w.n_burn && w.burn_row >= 0) {  // state the first output frame starts from
-      double *qfin = ik_launch_args()->qfinal;
+      double *qfin = ik_args(Lk)->qfinal;
       if (qfin)
         for (int i = lane; i < nq; i += 64) qfin[(size_t)w.burn_row * nq + i] = q[i];
     }
@@ -1182,7 +1190,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
     // ---- target preparation (update_targets: scale_human_data + offset_human_data, table-1 offsets) ----
     {
       double hp[3] = {0, 0, 0}, hq[4] = {1, 0, 0, 0}, rp[3];
-      IkLaunchK *La = ik_launch_args();
+      IkLaunchK *La = ik_args(Lk);
       const int64_t base = f * La->n_cols;
       if (La->in_f64) {
         const double *P = (const double *)La->hpos, *Q = (const double *)La->hquat;
@@ -1306,7 +1314,8 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
           if (quad) task_block_quad(ts, e, jl_kap, jl_bet, t_rs, t_xb, t_wp, t_wr, Bt + kBT * tl);
           else task_block(t_body, xpos, xquat, e, jl_kap, jl_bet, t_wp, t_wr, Bt + kBT * tl);
         }
-        const double diag = ik_launch_args()->prm.damping + ik_launch_args()->prm.lm_damping * sum_mu;
+        const double diag = ik_args(Lk)->prm.damping + ik_args(Lk)->prm.lm_damping * sum_mu;
+        const double lgain_generic = SQ ? 0.0 : ik_args(Lk)->prm.limit_gain;  // (read here, in uniform control flow)
         GMR_STAMP(3);
         // ---- screws S_i (world frame, about the origin) ----
         double Si[6] = {0, 0, 0, 0, 0, 0};
@@ -1382,9 +1391,8 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
           if (!SQ && a_lim) {  // mink ConfigurationLimit: -gain (q - lower) <= dq <= gain (upper - q)
             const double qv = q[a_qadr];
             const int ar = launder(2 * lane);
-            const double lgain = ik_launch_args()->prm.limit_gain;
-            lo = -lgain * (qv - m.arange[ar]);
-            hi = lgain * (m.arange[ar + 1] - qv);
+            lo = -lgain_generic * (qv - m.arange[ar]);
+            hi = lgain_generic * (m.arange[ar + 1] - qv);
           }
         }
         __syncthreads();  // Bc / poses are dead from here: H overwrites them
@@ -1442,7 +1450,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
           const double s_ci = sq_own ? c_in : 0.0;
           // mink ConfigurationLimit, evaluated by the lane that owns the dof in the QP layout: -gain (q - lower) <= dq <= gain (upper - q)
           const double qv = q[sq_qadr];
-          const double lgain = ik_launch_args()->prm.limit_gain;
+          const double lgain = ik_args(Lk)->prm.limit_gain;
           const double s_lo = fmax(-lgain * (qv - sq_rlo), -1e30), s_hi = fmin(lgain * (sq_rhi - qv), 1e30);
           double xs;
 #ifdef GMR_DUP_PHASE
@@ -1491,31 +1499,72 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
         GMR_STAMP(2);
         if (!first) ++num_iter;
         first = false;
-        if (!(curr - next > ik_launch_args()->prm.tol && num_iter < ik_launch_args()->prm.max_iter)) break;
+        if (!(curr - next > ik_args(Lk)->prm.tol && num_iter < ik_args(Lk)->prm.max_iter)) break;
         curr = next;
       }
     }
     if (kf >= w.n_burn) {
-      IkLaunchK *Lo = ik_launch_args();
+      IkLaunchK *Lo = ik_args(Lk);
       double *qout = Lo->qout;
       int *itp = Lo->iters;
       for (int i = lane; i < nq; i += 64) qout[(size_t)f * nq + i] = q[i];
       if (itp && lane == 0) itp[f] = solves | (qpflag << 30);
       ++out_done;
       if (w.check_stride > 0 && --left == 0) {  // a chunk solved here: its final state
-        double *Fk = ik_launch_args()->qfinal + (size_t)(w.final_row + kc) * nq;
+        double *Fk = ik_args(Lk)->qfinal + (size_t)(w.final_row + kc) * nq;
         for (int i = lane; i < nq; i += 64) Fk[i] = q[i];
         ++kc;
       }
     }
     __syncthreads();
   }
-  if (L.frames_done && lane == 0) L.frames_done[L.order[blockIdx.x]] = out_done;
-  if (w.check_stride == 0 && w.final_row >= 0 && L.qfinal)
-    for (int i = lane; i < nq; i += 64) L.qfinal[(size_t)w.final_row * nq + i] = q[i];
+  {
+    IkLaunchK *Le = ik_args(Lk);
+    int *fdone = Le->frames_done;
+    if (fdone && lane == 0) fdone[Le->order[item]] = out_done;
+    double *qfin = Le->qfinal;
+    if (w.check_stride == 0 && w.final_row >= 0 && qfin)
+      for (int i = lane; i < nq; i += 64) qfin[(size_t)w.final_row * nq + i] = q[i];
+  }
 #ifdef GMR_IK_STAMPS
-  if (lane == 0 && L.dbg)
-    for (int i = 0; i < 16; i++) atomicAdd(L.dbg + i, stamp_acc[i]);
+  if (lane == 0 && Lk->dbg)
+    for (int i = 0; i < 16; i++) atomicAdd(Lk->dbg + i, stamp_acc[i]);
+#endif
+}
+
+// One model per launch: the launch arguments are the kernel's own (IkLaunch is the second kernel argument, offset 8 behind the
+// model pointer in the kernarg segment).
+template <int NVP, bool SQ>
+__global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const DevModel *__restrict__ mp, IkLaunch L, LdsLayout lay) {
+  IkLaunchK *Lk = (IkLaunchK *)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + 8);
+  ik_body<NVP, SQ>(*(DevModelG *)mp, Lk, lay, (int)blockIdx.x);
+}
+
+// Several models in ONE launch (BASELINE config 4: heterogeneous trees): every workgroup looks up the entry its work item belongs
+// to -- model, launch arguments (its own input / output arrays and columns) and LDS layout -- and runs the same body.  All
+// members are built for one kernel variant (the host forces a common NVP; gmr_group_create).
+struct IkGroupEntry {
+  const DevModel *m;
+  IkLaunch L;
+  LdsLayout lay;
+  int item_base, pad;  // first workgroup of this entry
+};
+template <int NVP, bool SQ>
+__global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_group_kernel(const IkGroupEntry *__restrict__ entries,
+                                                                             const int *__restrict__ block_entry) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass only needs the kernel's stub; address-space-qualified copies do not parse there)
+  // (readfirstlane: tell the compiler these are wave-uniform, so that everything derived from them stays in SGPRs)
+  const int e = __builtin_amdgcn_readfirstlane(block_entry[blockIdx.x]);
+  const uintptr_t ea = (uintptr_t)(entries + e);
+  const uintptr_t eu = (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ea) |
+                       ((uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ea >> 32)) << 32);
+  const auto *E = (const IkGroupEntry __attribute__((address_space(4))) *)eu;
+  LdsLayout lay;  // (field by field: every member a scalar load into SGPRs)
+#define GMR_LAY(f) lay.f = E->lay.f;
+  GMR_LAY(zero) GMR_LAY(hplan) GMR_LAY(cplan) GMR_LAY(q) GMR_LAY(tp) GMR_LAY(tq) GMR_LAY(S) GMR_LAY(F) GMR_LAY(Lb) GMR_LAY(bodyc)
+  GMR_LAY(xpos) GMR_LAY(xquat) GMR_LAY(B) GMR_LAY(Bc) GMR_LAY(H) GMR_LAY(total_doubles)
+#undef GMR_LAY
+  ik_body<NVP, SQ>(*(DevModelG *)E->m, &E->L, lay, (int)blockIdx.x - E->item_base);
 #endif
 }
 
@@ -1536,7 +1585,7 @@ struct EvalLaunch {
 };
 
 __global__ void __launch_bounds__(64) eval_kernel(const DevModel *__restrict__ mp, EvalLaunch L, LdsLayout lay) {
-  const DevModel &m = *mp;
+  DevModelG &m = *(DevModelG *)mp;
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
   const long long f = blockIdx.x;

@@ -27,17 +27,21 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 class Engine:
-    def __init__(self, cm: CompiledModel, device: int = 0):
+    def __init__(self, cm: CompiledModel, device: int = 0, _borrowed_handle=None):
         if not torch.cuda.is_available():
             raise EngineError("no HIP device visible to torch: the gmr_amd engine has no CPU path")
         self._lib = _native.load()
         self.cm = cm
         self.device_index = int(device)
         self.device = torch.device("cuda", self.device_index)
-        err = C.create_string_buffer(512)
-        self._h = self._lib.gmr_model_create(cm.blob, len(cm.blob), self.device_index, err, len(err))
-        if not self._h:
-            raise EngineError(f"gmr_model_create: {err.value.decode()}")
+        self._owns = _borrowed_handle is None
+        if _borrowed_handle is not None:  # a member of an EngineGroup: the group owns the handle
+            self._h = _borrowed_handle
+        else:
+            err = C.create_string_buffer(512)
+            self._h = self._lib.gmr_model_create(cm.blob, len(cm.blob), self.device_index, err, len(err))
+            if not self._h:
+                raise EngineError(f"gmr_model_create: {err.value.decode()}")
         info = ModelInfo()
         self._lib.gmr_model_info_get(self._h, C.byref(info))
         self.info = info
@@ -45,7 +49,8 @@ class Engine:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.gmr_model_destroy(self._h)
+            if self._owns:
+                self._lib.gmr_model_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -330,6 +335,82 @@ class Engine:
                                          offs.ctypes.data_as(C.c_void_p), len(offs) - 1, _ptr(out), self._stream())
         self._check(rc, "gmr_fk_min_height")
         return out
+
+
+class EngineGroup:
+    """Several robots' batches in ONE launch (``gmr_group_*``; BASELINE config 4, "heterogeneous trees in one launch").
+
+    The members are built for one common kernel variant; ``ik_solve`` takes one batch per member and runs all their work items
+    in a single grid.  ``engines[i]`` is member i as an ordinary ``Engine`` (FK, evaluate, sessions, its own launches).
+    """
+
+    def __init__(self, cms, device: int = 0):
+        if not torch.cuda.is_available():
+            raise EngineError("no HIP device visible to torch: the gmr_amd engine has no CPU path")
+        self._lib = _native.load()
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        n = len(cms)
+        blobs = (C.c_char_p * n)(*[cm.blob for cm in cms])
+        sizes = (C.c_size_t * n)(*[len(cm.blob) for cm in cms])
+        err = C.create_string_buffer(512)
+        self._g = self._lib.gmr_group_create(blobs, sizes, n, self.device_index, err, len(err))
+        if not self._g:
+            raise EngineError(f"gmr_group_create: {err.value.decode()}")
+        self.engines = [Engine(cm, device, _borrowed_handle=self._lib.gmr_group_model(self._g, i)) for i, cm in enumerate(cms)]
+
+    def close(self):
+        if getattr(self, "_g", None):
+            for e in self.engines:
+                e.close()
+            self._lib.gmr_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def ik_solve(self, batches, params: Optional[IKParams] = None):
+        """``batches[i] = (pos, quat, slot_col, items)`` for member i (or ``None``: no work) -> list of (qpos, iters) per member."""
+        if len(batches) != len(self.engines):
+            raise EngineError("one batch (or None) per group member")
+        prm = params or IKParams()
+        inputs = (_native.GroupInput * len(batches))()
+        keep, outs = [], []
+        for i, (eng, b) in enumerate(zip(self.engines, batches)):
+            if b is None:
+                outs.append((None, None))
+                continue
+            pos, quat, slot_col, items = b
+            if pos.device != self.device or quat.device != self.device or pos.dtype != quat.dtype or pos.dtype not in (torch.float32, torch.float64) \
+                    or pos.dim() != 3 or quat.dim() != 3 or pos.shape[2] != 3 or quat.shape[2] != 4 or pos.shape[:2] != quat.shape[:2]:
+                raise EngineError(f"member {i}: bad key-point tensors")
+            pos, quat = pos.contiguous(), quat.contiguous()
+            N, B = int(pos.shape[0]), int(pos.shape[1])
+            items = np.ascontiguousarray(items, dtype=_native.WORK_ITEM_DTYPE)
+            slot_col = np.ascontiguousarray(slot_col, dtype=np.int32)
+            if slot_col.shape != (eng.info.nslot,):
+                raise EngineError(f"member {i}: slot_col has the wrong length")
+            if len(items) and (int(items["init_row"].max()) >= 0 or int(items["final_row"].max()) >= 0 or int(items["burn_row"].max()) >= 0):
+                raise EngineError("group launches take plain per-clip items (no state rows)")
+            out = torch.full((N, eng.nq), float("nan"), dtype=torch.float64, device=self.device)
+            iters = torch.zeros(N, dtype=torch.int32, device=self.device)
+            outs.append((out, iters))
+            keep += [pos, quat, items, slot_col]
+            if N == 0 or len(items) == 0:
+                continue
+            inputs[i].human_pos, inputs[i].human_quat = pos.data_ptr(), quat.data_ptr()
+            inputs[i].in_dtype = _native.GMR_DTYPE_F64 if pos.dtype == torch.float64 else _native.GMR_DTYPE_F32
+            inputs[i].n_cols, inputs[i].slot_col, inputs[i].n_frames = B, slot_col.ctypes.data, N
+            inputs[i].items, inputs[i].n_items = items.ctypes.data, len(items)
+            inputs[i].qpos_out, inputs[i].iters_out = out.data_ptr(), iters.data_ptr()
+        rc = self._lib.gmr_group_ik_solve(self._g, inputs, C.byref(prm), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        if rc != 0:
+            msg = self._lib.gmr_group_last_error(self._g)
+            raise EngineError(f"gmr_group_ik_solve: {_ERR.get(rc, rc)}: {msg.decode() if msg else ''}")
+        return outs
 
 
 class Session:

@@ -22,6 +22,7 @@
  *                      (motion_retarget.py:117-200) and, inside it, mink.solve_ik +
  *                      Configuration.integrate_inplace (call sites motion_retarget.py:147-150,156-159,
  *                      166-169,176-179)
+ *   gmr_group_*        several robots' batches in one launch (one GeneralMotionRetargeting per robot in the reference)
  *   gmr_session_*      the live loop of scripts/optitrack_to_robot.py:37-46 / smplx_to_robot.py:103-126 / bvh_to_robot.py:
  *                      one frame in, one qpos out, state carried inside (`retargeter.retarget(frame)` called once per
  *                      captured frame): a latency path next to the throughput path of gmr_ik_solve
@@ -109,6 +110,34 @@ int gmr_ik_solve(gmr_model *m, const void *human_pos, const void *human_quat, in
                  const int32_t *slot_col, int64_t n_frames, const gmr_work_item *items, int n_items,
                  const gmr_ik_params *params, const double *qpos_init, double *qpos_final, double *qpos_out,
                  int32_t *iters_out, int32_t *frames_done, gmr_ik_stats *stats, void *stream);
+
+/* Several models in ONE launch (BASELINE config 4, "heterogeneous trees in one launch"): a group owns n models built for one
+ * common kernel variant; gmr_group_ik_solve runs every member's work items in a single grid -- each wavefront looks up its
+ * member's model, LDS layout and input / output arrays.  The reference analogue is one GeneralMotionRetargeting per robot in
+ * the workers of one mp.Pool (scripts/smplx_to_robot_dataset.py:79-83, 241-242).
+ *   gmr_group_create   blobs / blob_bytes host [n_models]: one packed model each (gmr_blob.h); NULL + message on failure
+ *   gmr_group_model    borrowed handle of member i for everything else (gmr_fk, gmr_evaluate, sessions, gmr_ik_solve alone);
+ *                      members are destroyed with the group
+ *   gmr_group_ik_solve inputs host [n_models], member i's arguments exactly as gmr_ik_solve takes them (n_items = 0: no work
+ *                      for that member); params are shared; asynchronous on `stream`                                        */
+typedef struct gmr_group gmr_group;
+typedef struct gmr_group_input {
+  const void *human_pos, *human_quat; /* device */
+  int32_t in_dtype, n_cols;
+  const int32_t *slot_col;            /* host [nslot of member i] */
+  int64_t n_frames;
+  const gmr_work_item *items;         /* host [n_items] */
+  int32_t n_items, reserved;
+  const double *qpos_init;            /* device or NULL */
+  double *qpos_final, *qpos_out;      /* device (qpos_final may be NULL) */
+  int32_t *iters_out, *frames_done;   /* device or NULL */
+} gmr_group_input;
+gmr_group *gmr_group_create(const void *const *blobs, const size_t *blob_bytes, int n_models, int device, char *err, size_t err_len);
+void gmr_group_destroy(gmr_group *g);
+int gmr_group_size(const gmr_group *g);
+gmr_model *gmr_group_model(gmr_group *g, int i);
+const char *gmr_group_last_error(const gmr_group *g);
+int gmr_group_ik_solve(gmr_group *g, const gmr_group_input *inputs, const gmr_ik_params *params, void *stream);
 
 /* Single-sequence sessions ("teleop"): one frame per call, warm start carried in the session -- the semantics of calling
  * GeneralMotionRetargeting.retarget once per captured frame (motion_retarget.py:139-185).  Inputs and outputs are HOST

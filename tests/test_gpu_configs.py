@@ -118,6 +118,40 @@ def test_config4_five_robots_concurrently_full_size():
         assert np.abs(q[:120].cpu().numpy() - q_ref).max() < 1e-6
 
 
+def test_config4_five_robots_in_one_launch():
+    """BASELINE config 4 as worded: heterogeneous trees in ONE launch.  EngineGroup builds the five robots for a common kernel variant
+    (NVP 36, structured QP) and gmr_group_ik_solve runs 5 x 64 clips x 1000 frames as one grid of 320 wavefronts, each looking up
+    its own model, LDS layout and arrays.  Every member's result must be bitwise what its own single-model launch gives (members
+    rebuilt for a larger NVP included: padding rows do not change the arithmetic), and the oracle's to 1e-6."""
+    from gmr_amd.engine import EngineGroup
+    robots = ["unitree_g1", "booster_t1", "stanford_toddy", "fourier_n1", "engineai_pm01"]
+    cms = [compiled("smplx", r) for r in robots]
+    grp = EngineGroup(cms, 0)
+    assert len({e.info.nv_padded for e in grp.engines}) == 1 and grp.engines[0].info.nv_padded == 36
+    dev = grp.device
+    batches, offs = [], np.arange(65, dtype=np.int64) * 1000
+    for cm in cms:
+        pos, quat, names, _, _ = synth.synth_clips(cm, 8, 1000, seed=41, hard=True, dtype=np.float32)
+        rep = lambda a: torch.from_numpy(a).to(dev).repeat(8, 1, 1)  # noqa: E731
+        batches.append((rep(pos), rep(quat), cm.slot_columns(names), make_items(offs)))
+    outs = grp.ik_solve(batches)
+    torch.cuda.synchronize()
+    for cm, eng, b, (q, it) in zip(cms, grp.engines, batches, outs):
+        _check_invariants(cm, q, it, 64000)
+        q1, it1, _ = _engine(cm).ik_solve(b[0], b[1], b[2], b[3])            # the member alone, built for its own variant
+        assert torch.equal(q, q1) and torch.equal(it, it1)
+        q2, it2, _ = eng.ik_solve(b[0], b[1], b[2], b[3])                     # the group's handle, single-model launch
+        assert torch.equal(q, q2) and torch.equal(it, it2)
+        q_ref, it_ref, _ = Oracle(cm.blob).ik_solve(b[0][:150].cpu().numpy(), b[1][:150].cpu().numpy(), b[2], make_items([0, 150]))
+        assert np.abs(q[:150].cpu().numpy() - q_ref).max() < 1e-6 and np.array_equal(it[:150].cpu().numpy() & 0x3FFFFFFF, it_ref)
+    # a member without work, and unequal batch sizes
+    small = [None, (batches[1][0][:3000], batches[1][1][:3000], batches[1][2], make_items(offs[:4])), None, None,
+             (batches[4][0][:1000], batches[4][1][:1000], batches[4][2], make_items(offs[:2]))]
+    o2 = grp.ik_solve(small)
+    assert o2[0] == (None, None) and torch.equal(o2[1][0], outs[1][0][:3000]) and torch.equal(o2[4][0], outs[4][0][:1000])
+    grp.close()
+
+
 def test_config5_hands_model_full_size():
     """unitree_g1_with_hands (43 hinges, deepest tree) over 2048 clips x 3000 frames = 6.1 M frames in one launch."""
     cm = compiled("smplx", "unitree_g1_with_hands")
