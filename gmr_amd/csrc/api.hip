@@ -1023,6 +1023,8 @@ int gmr_group_ik_solve(gmr_group *g, const gmr_group_input *inputs, const gmr_ik
     m->err.clear();
     const gmr_group_input &in = inputs[i];
     gmr::IkLaunch L{};
+    entries[i] = gmr::IkGroupEntry{};
+    if (in.n_items == 0) continue;  // no work for this member
     int rc = prepare_ik_launch(m, in.human_pos, in.human_quat, in.in_dtype, in.n_cols, in.slot_col, in.n_frames, in.items, in.n_items, params,
                                in.qpos_init, in.qpos_final, in.qpos_out, in.iters_out, in.frames_done, nullptr, st, scratch[i], L, sorted[i]);
     if (rc != GMR_OK) { g->err = "member " + std::to_string(i) + ": " + m->err; return rc; }
