@@ -516,6 +516,12 @@ static double stage_error(const oracle_model *m, int tab, const double *xpos, co
 /* mink.solve_ik's QP for one table at the current configuration:
  *   H = damping I + sum_t [ (W J)'(W J) + lm |W e|^2 I ],  c = sum_t (W J)'(W e)
  *   box: -gain (q - lower) <= dq <= gain (upper - q) on limited hinges.          */
+/* Experiment switch (tests / tools only): 1 = emulate a mixed-precision assembly -- the weighted Jacobian rows and residuals
+ * rounded to float32 and H, c accumulated in float32 (what packed v_pk_fma_f32 task blocks / composites / H pairs would carry),
+ * everything else (FK, residual, LM damping, QP, termination test) in float64.  0 = the reference's float64 throughout. */
+static int g_mixed_assembly = 0;
+void oracle_set_mixed_assembly(int on) { g_mixed_assembly = on; }
+
 void oracle_build_qp(const oracle_model *m, int tab, const gmr_ik_params *prm, const double *qpos, const double *xpos, const double *xquat,
                      const double *tp, const double *tq, const double *e_all, double *H, double *c, double *lo, double *hi) {
   int nv = m->h.nv;
@@ -532,6 +538,20 @@ void oracle_build_qp(const oracle_model *m, int tab, const gmr_ik_params *prm, c
       we2 += (w[i] * e[i]) * (w[i] * e[i]);
     }
     diag += prm->lm_damping * we2;
+    if (g_mixed_assembly) {
+      for (int i = 0; i < 6; i++) {
+        if (w[i] == 0) continue;
+        const double *Ji = J + i * nv;
+        float wei = (float)(w[i] * e[i]);
+        for (int k = 0; k < nv; k++) {
+          if (Ji[k] == 0) continue;
+          float a = (float)(w[i] * Ji[k]);
+          c[k] = (double)((float)c[k] + a * wei);
+          for (int l = 0; l < nv; l++) H[k * nv + l] = (double)((float)H[k * nv + l] + a * (float)(w[i] * Ji[l]));
+        }
+      }
+      continue;
+    }
     for (int i = 0; i < 6; i++) {
       double w2 = w[i] * w[i];
       if (w2 == 0) continue;

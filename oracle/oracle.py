@@ -70,6 +70,7 @@ def lib():
         L.oracle_stage_error.restype = C.c_double
         L.oracle_stage_error.argtypes = [vp, C.c_int, dp, dp, dp, dp]
         L.oracle_build_qp_at.argtypes = [vp, C.c_int, C.POINTER(IKParams), dp, dp, dp, dp, dp, dp, dp]
+        L.oracle_set_mixed_assembly.argtypes = [C.c_int]
         for f in ("oracle_nq", "oracle_nv", "oracle_nbody"):
             getattr(L, f).restype = C.c_int
             getattr(L, f).argtypes = [vp]
@@ -203,6 +204,11 @@ class Oracle:
         if rc != 0:
             raise RuntimeError("oracle QP failed")
         return (qout, iters, qf, done) if want_done else (qout, iters, qf)
+
+
+def set_mixed_assembly(on: bool) -> None:
+    """Experiment switch of the oracle (tools/experiments/mixed_precision_emulation.py): float32 H / c assembly."""
+    lib().oracle_set_mixed_assembly(int(bool(on)))
 
 
 def box_qp(H, c, lo, hi):
