@@ -40,11 +40,11 @@ FP64_VECTOR_PEAK_TF = 78.6  # AMD MI355X datasheet; = 1/2 of the guide's 157.3 T
 ROBOT, SRC = "unitree_g1", "smplx"
 
 # HBM bytes per output frame of ik_kernel measured with rocprofv3 PMC passes (profiles/r01_v17_pmc_*: 2 x FETCH_SIZE
-# (gfx950 counts half, MI355X_MICROARCH.md "HBM") + WRITE_SIZE over an 8192 x 600 = 4.9152e6-frame launch):
+# (gfx950 counts half, MI355X_MICROARCH.md "HBM") + WRITE_SIZE over an 8192 x 600 = 4.9152e6-frame launch; round 2 re-measured):
 # 1.93 GB read + 1.44 GB written = 685 B/frame (393 + 292) against 684 algorithmic.  Valid for THIS configuration only
 # (unitree_g1 / smplx / float32 key-points); any other launch reports its algorithmic bytes and says so.
 MEASURED_TRAFFIC = {"robot": "unitree_g1", "src": "smplx", "in_itemsize": 4,
-                    "bytes_per_frame": (2 * 942730.6 * 1024 + 1401605.1 * 1024) / 4915200.0, "source": "profiles/r01_v17_pmc_*"}
+                    "bytes_per_frame": (2 * 942970.5 * 1024 + 1401604.3 * 1024) / 4915200.0, "source": "profiles/r02_v18_pmc_*"}
 
 
 def parse_args(argv=None):
@@ -289,41 +289,45 @@ def main():
 
     # ------------------------------------------------------------------ N > 1: the exchange steps, on the real outputs
     if world > 1 and not args.hot_only:
-        cdev = dev if on_rccl else torch.device("cpu")
-        ones = torch.ones(1, dtype=torch.float64, device=cdev)
-        torch.distributed.all_reduce(ones)
-        # all-gather of qpos (north_star: "allgather of qpos over xGMI"): a bounded sample of this rank's output rows
-        ns_clips = min(S, 1024)
-        lengths = [T] * (ns_clips * world)
-        mine = gdist.my_clips(lengths)
-        local_rows = out[: len(mine) * T]
-        torch.cuda.synchronize()
-        barrier()
-        t0 = time.perf_counter()
-        full = gdist.gather_rows(local_rows, lengths)
-        torch.cuda.synchronize()
-        barrier()
-        t_ag = max_over_ranks(time.perf_counter() - t0)
-        ok_rows = bool(full.shape[0] == ns_clips * world * T)
-        del full
-        # strong scaling: the SAME S clips split over the ranks (longest-first greedy; equal lengths -> S / world each)
-        s_mine = gdist.my_clips([T] * S)
-        s_items = make_items(np.arange(len(s_mine) + 1, dtype=np.int64) * T)
-        n_s = len(s_mine) * T
-        st_el, _, _ = timed_steps(lambda: eng.ik_solve(pos[:n_s], quat[:n_s], sc, s_items, out=out[:n_s]), args.steps, 1)
-        # few long clips (BASELINE config 3): a LAFAN1-sized set, chunks of every clip spread over all ranks
-        lc = long_clip_set(cm, synth, dev, yaw0=1.0)
-        lc_el, _, (q_lc, _, lc_info) = timed_steps(lambda: lc["eng"].ik_solve_chunked_sharded(lc["pos"], lc["quat"], lc["sc"], lc["offs"], 64, 32), 2, 1)
-        if rank == 0:
-            result["collectives"] = {
-                "backend": torch.distributed.get_backend(), "rccl_ranks": int(ones.item()),
-                "allgather_qpos_ms": 1e3 * t_ag, "allgather_rows_per_rank": int(local_rows.shape[0]), "allgather_bytes_per_rank": int(local_rows.shape[0]) * eng.nq * 8,
-                "allgather_GBps_received_per_rank": int(local_rows.shape[0]) * eng.nq * 8 * (world - 1) / t_ag / 1e9, "allgather_complete": ok_rows,
-                "note": f"gather_rows of {ns_clips} clips x {T} frames of real output per rank (288 B/frame) to every rank; outside the timed region of `value`",
-            }
-            result["strong"] = {"clips_total": S, "frames_per_step": S * T, "value": S * T * args.steps / st_el, "ms_per_step": 1e3 * st_el / args.steps}
-            result["long_clips_sharded"] = {"set": "heading_within_1rad", "clips": len(lc["offs"]) - 1, "frames": int(lc["offs"][-1]), "frames_per_s": 2 * int(lc["offs"][-1]) / lc_el,
-                                            "chunk": 64, "burn_in": 32, **{k: lc_info[k] for k in ("chunks", "resolved_frames", "resolved_chunks", "ranks")}}
+        try:
+            cdev = dev if on_rccl else torch.device("cpu")
+            ones = torch.ones(1, dtype=torch.float64, device=cdev)
+            torch.distributed.all_reduce(ones)
+            # all-gather of qpos (north_star: "allgather of qpos over xGMI"): a bounded sample of this rank's output rows
+            ns_clips = min(S, 1024)
+            lengths = [T] * (ns_clips * world)
+            mine = gdist.my_clips(lengths)
+            local_rows = out[: len(mine) * T]
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            full = gdist.gather_rows(local_rows, lengths)
+            torch.cuda.synchronize()
+            barrier()
+            t_ag = max_over_ranks(time.perf_counter() - t0)
+            ok_rows = bool(full.shape[0] == ns_clips * world * T)
+            del full
+            # strong scaling: the SAME S clips split over the ranks (longest-first greedy; equal lengths -> S / world each)
+            s_mine = gdist.my_clips([T] * S)
+            s_items = make_items(np.arange(len(s_mine) + 1, dtype=np.int64) * T)
+            n_s = len(s_mine) * T
+            st_el, _, _ = timed_steps(lambda: eng.ik_solve(pos[:n_s], quat[:n_s], sc, s_items, out=out[:n_s]), args.steps, 1)
+            # few long clips (BASELINE config 3): a LAFAN1-sized set, chunks of every clip spread over all ranks
+            lc = long_clip_set(cm, synth, dev, yaw0=1.0)
+            lc_el, _, (q_lc, _, lc_info) = timed_steps(lambda: lc["eng"].ik_solve_chunked_sharded(lc["pos"], lc["quat"], lc["sc"], lc["offs"], 64, 32), 2, 1)
+            if rank == 0:
+                result["collectives"] = {
+                    "backend": torch.distributed.get_backend(), "rccl_ranks": int(ones.item()),
+                    "allgather_qpos_ms": 1e3 * t_ag, "allgather_rows_per_rank": int(local_rows.shape[0]), "allgather_bytes_per_rank": int(local_rows.shape[0]) * eng.nq * 8,
+                    "allgather_GBps_received_per_rank": int(local_rows.shape[0]) * eng.nq * 8 * (world - 1) / t_ag / 1e9, "allgather_complete": ok_rows,
+                    "note": f"gather_rows of {ns_clips} clips x {T} frames of real output per rank (288 B/frame) to every rank; outside the timed region of `value`",
+                }
+                result["strong"] = {"clips_total": S, "frames_per_step": S * T, "value": S * T * args.steps / st_el, "ms_per_step": 1e3 * st_el / args.steps}
+                result["long_clips_sharded"] = {"set": "heading_within_1rad", "clips": len(lc["offs"]) - 1, "frames": int(lc["offs"][-1]), "frames_per_s": 2 * int(lc["offs"][-1]) / lc_el,
+                                                "chunk": 64, "burn_in": 32, **{k: lc_info[k] for k in ("chunks", "resolved_frames", "resolved_chunks", "ranks")}}
+        except Exception as ex:  # the headline line must survive a failure of the extra legs
+            if rank == 0:
+                result["multi_gpu_legs_error"] = repr(ex)
 
     # ------------------------------------------------------------------ N = 1: the other kernels and modes of the path
     if rank == 0 and world == 1 and (not args.hot_only or args.hot_fk):
@@ -396,6 +400,12 @@ def main():
                                            "max_abs_diff_vs_sequential": float((q_chk - q_seq).abs().max().item()),
                                            "frames_with_different_solve_count": int((it_chk != it_seq).sum().item())}
             del lc
+        # BASELINE config 4: five robots' batches (5 x 64 clips x 1000 frames) as ONE launch (gmr_group_*) and as five launches on
+        # five streams (round 1's form)
+        try:
+            result["heterogeneous"] = heterogeneous_leg(dev, synth, make_items, timed)
+        except Exception as ex:
+            result["heterogeneous"] = {"error": repr(ex)}
         # live single-sequence mode (gmr_session_*): host frame in -> host qpos out, one launch per frame
         ses = eng.session(sc, int(pos.shape[1]), dtype=np.float32)
         hp, hq = pos[:256].cpu().numpy(), quat[:256].cpu().numpy()
@@ -493,6 +503,42 @@ def _dataset_device(gmr, dataset, pos, quat, names, offs):
     root_pos[:, 2] -= torch.repeat_interleave(lowest, lens)
     root_pos[:, :2] -= torch.repeat_interleave(root_pos[torch.from_numpy(offs[:-1]).to(qpos.device), :2], lens, dim=0)
     return root_pos, root_rot, local_body_pos
+
+
+def heterogeneous_leg(dev, synth, make_items, timed):
+    import numpy as np
+    import torch
+    from gmr_amd import params
+    from gmr_amd.engine import EngineGroup
+    from gmr_amd.ik_config import load_ik_config
+    from gmr_amd.mjcf import load_robot
+    from gmr_amd.model import compile_model
+    robots = ["unitree_g1", "booster_t1", "stanford_toddy", "fourier_n1", "engineai_pm01"]
+    cms = [compile_model(load_robot(params.ROBOT_XML_DICT[r], name=r), load_ik_config(params.IK_CONFIG_DICT[SRC][r])) for r in robots]
+    grp = EngineGroup(cms, dev.index)
+    offs = np.arange(65, dtype=np.int64) * 1000
+    batches = []
+    for cm in cms:
+        pos, quat, names, _, _ = synth.synth_clips(cm, 8, 1000, seed=41, hard=True, dtype=np.float32)
+        batches.append((torch.from_numpy(pos).to(dev).repeat(8, 1, 1), torch.from_numpy(quat).to(dev).repeat(8, 1, 1), cm.slot_columns(names), make_items(offs)))
+    nfr = 5 * 64 * 1000
+    t_one, outs = timed(lambda: grp.ik_solve(batches), reps=5)
+    streams = [torch.cuda.Stream(dev) for _ in robots]
+
+    def five():
+        r = []
+        for e, b, st in zip(grp.engines, batches, streams):
+            st.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(st):
+                r.append(e.ik_solve(b[0], b[1], b[2], b[3]))
+        for st in streams:
+            torch.cuda.current_stream(dev).wait_stream(st)
+        return r
+    t_five, outs5 = timed(five, reps=5)
+    same = all(torch.equal(a[0], b[0]) for a, b in zip(outs, outs5))
+    grp.close()
+    return {"robots": robots, "frames": nfr, "one_launch_frames_per_s": nfr / t_one, "five_launches_frames_per_s": nfr / t_five,
+            "kernel_variant_nv_padded": 36, "bitwise_equal": bool(same)}
 
 
 def long_clip_set(cm_unused, synth, dev, n_clips=77, seed=3, yaw0=None):
