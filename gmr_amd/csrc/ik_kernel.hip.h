@@ -74,6 +74,20 @@ typedef unsigned long long u64;
 // stride is 30 = 15 sixteen-byte slots, odd, so that the blocks of different composites start on different LDS slots: the F
 // phase (every dof lane reads element c of ITS composite) then has no bank conflicts (stride 28 = 14 slots: 91 extra LDS
 // cycles per solve on G1).  Stored "by column": element 3k + s, s = 0..2,
+// GMR_IK_MIXED (variant builds only, tools/build_variant.sh mixed -DGMR_IK_MIXED=1): the assembly of H and c -- task blocks,
+// composites, screws as stored, F = B S, the H pair dot products -- in float32 (blocks / S / F keep their LDS slots and strides,
+// so every host-made plan stays valid; they just fill the first half of each slot), everything that decides the trajectory
+// (FK, residuals and their norm, LM damping, the QP with its pivots, integration, the termination test) in float64.  The
+// oracle's emulation of the same split (tools/experiments/mixed_precision_emulation.py): max |dq| 3.4e-6 rad, no frame with a
+// different solve count in 96 000.
+#ifndef GMR_IK_MIXED
+#define GMR_IK_MIXED 0
+#endif
+#if GMR_IK_MIXED
+typedef float blk_t;
+#else
+typedef double blk_t;
+#endif
 constexpr int kBT = 30, kBTLanes = 14;
 // k: 0 LL(s,s)  1 LL(s,s+1)  2..4 LA(s,s), LA(s,s+1), LA(s,s+2)  5 AA(s,s)  6 AA(s,s+1)  7 gl_s  8 ga_s   (indices mod 3)
 // -- the order in which three lanes per task (one per column s) produce it in task_block_quad
@@ -632,7 +646,8 @@ __device__ __forceinline__ void task_block(int body, const double *xpos, const d
 }
 
 // y = B [m; a] for a 6x6 symmetric block [[LL, LA],[LA', AA]] in the layout of kBT
-__device__ __forceinline__ void sym6_mul(const double *B, const double m[3], const double a[3], double fl[3], double fa[3]) {
+template <class T>
+__device__ __forceinline__ void sym6_mul(const T *B, const T m[3], const T a[3], T fl[3], T fa[3]) {
 #pragma unroll
   for (int i = 0; i < 3; i++) {
     fl[i] = B[bt_ll(i, 0)] * m[0] + B[bt_ll(i, 1)] * m[1] + B[bt_ll(i, 2)] * m[2] + B[bt_la(i, 0)] * a[0] + B[bt_la(i, 1)] * a[1] + B[bt_la(i, 2)] * a[2];
@@ -651,46 +666,61 @@ __device__ __forceinline__ double quad_get(double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
+template <int CTRL>
+__device__ __forceinline__ float quad_get(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ double pick3(double a, double b, double c, int s) { return s == 0 ? a : (s == 1 ? b : c); }
-__device__ __forceinline__ void task_block_quad(int s, const double e[6], double kap, double bet, const double rs[3],
-                                                const double xb[3], double wp, double wr, double *out) {
-  const double *u = e, *ph = e + 3;
-  const double th2 = ph[0] * ph[0] + ph[1] * ph[1] + ph[2] * ph[2];
-  const double pu = ph[0] * u[0] + ph[1] * u[1] + ph[2] * u[2];
+template <class T>
+__device__ __forceinline__ void cross_t(const T a[3], const T b[3], T o[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+// T = double: the block in float64 (shipped).  T = float (GMR_IK_MIXED): the same arithmetic in float32 from rounded inputs.
+template <class T>
+__device__ __forceinline__ void task_block_quad(int s, const double e64[6], double kap64, double bet64, const double rs64[3],
+                                                const double xb64[3], double wp64, double wr64, T *out) {
+  const T e[6] = {(T)e64[0], (T)e64[1], (T)e64[2], (T)e64[3], (T)e64[4], (T)e64[5]};
+  const T kap = (T)kap64, bet = (T)bet64, wp = (T)wp64, wr = (T)wr64;
+  const T rs[3] = {(T)rs64[0], (T)rs64[1], (T)rs64[2]}, xb[3] = {(T)xb64[0], (T)xb64[1], (T)xb64[2]};
+  const T *u = e, *ph = e + 3;
+  const T th2 = ph[0] * ph[0] + ph[1] * ph[1] + ph[2] * ph[2];
+  const T pu = ph[0] * u[0] + ph[1] * u[1] + ph[2] * u[2];
   // mink SE3.ljacinv returns the identity below its threshold: kap = bet = 0 from the residual, and the two skew terms go too
-  const double hs = th2 < kLieEps ? 0.0 : 0.5;
+  const T hs = e64[3] * e64[3] + e64[4] * e64[4] + e64[5] * e64[5] < kLieEps ? (T)0 : (T)0.5;
   // A = I - 1/2 [ph]x + kap (ph ph' - th2 I);  Bo = -1/2 [u]x + kap (ph u' + u ph' - 2 pu I) + k2 (ph ph' - th2 I), k2 = -2 bet pu.
   // Only column s of U = A R' and of V = (Bo - A [xb]x) R' is needed here, i.e. A r, Bo r and A (xb x r) with r = row s of R
   // (xb = R' x, the body-frame position of the body origin, and r come from the residual of the same pose): the matrices are
   // applied in vector form, never built.
-  const double k2 = -2.0 * bet * pu, a0 = 1.0 - kap * th2;
-  auto dot = [](const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
-  auto applyA = [&](const double v[3], double pv, double o[3]) {  // A v, pv = ph . v
-    double c[3];
-    cross(ph, v, c);
-    const double bv = kap * pv;
+  const T k2 = (T)-2 * bet * pu, a0 = (T)1 - kap * th2;
+  auto dot = [](const T a[3], const T b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+  auto applyA = [&](const T v[3], T pv, T o[3]) {  // A v, pv = ph . v
+    T c[3];
+    cross_t(ph, v, c);
+    const T bv = kap * pv;
 #pragma unroll
     for (int i = 0; i < 3; i++) o[i] = a0 * v[i] - hs * c[i] + bv * ph[i];
   };
-  const double pr = dot(ph, rs), ur = dot(u, rs);
-  double uc[3], vc[3], w[3], aw[3], cu[3];
+  const T pr = dot(ph, rs), ur = dot(u, rs);
+  T uc[3], vc[3], w[3], aw[3], cu[3];
   applyA(rs, pr, uc);
-  cross(xb, rs, w);
+  cross_t(xb, rs, w);
   applyA(w, dot(ph, w), aw);
-  cross(u, rs, cu);
-  const double c_ph = kap * ur + k2 * pr, c_u = kap * pr, c_r = -2.0 * kap * pu - k2 * th2;
+  cross_t(u, rs, cu);
+  const T c_ph = kap * ur + k2 * pr, c_u = kap * pr, c_r = (T)-2 * kap * pu - k2 * th2;
 #pragma unroll
   for (int i = 0; i < 3; i++) vc[i] = c_ph * ph[i] + c_u * u[i] + c_r * rs[i] - hs * cu[i] - aw[i];
   // columns s+1 and s+2 from the quad neighbours (quad_perm [1,2,0,3] = 0xC9 and [2,0,1,3] = 0xD2)
-  double u1[3], v1[3], v2[3];
+  T u1[3], v1[3], v2[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) {
     u1[i] = quad_get<0xC9>(uc[i]); v1[i] = quad_get<0xC9>(vc[i]);
     v2[i] = quad_get<0xD2>(vc[i]);
   }
-  const double wp2 = wp * wp, wr2 = wr * wr;
-  const double uu = dot(uc, uc), uu1 = dot(uc, u1);
-  const double ev[3] = {wp2 * e[0], wp2 * e[1], wp2 * e[2]}, ew[3] = {wr2 * e[3], wr2 * e[4], wr2 * e[5]};
+  const T wp2 = wp * wp, wr2 = wr * wr;
+  const T uu = dot(uc, uc), uu1 = dot(uc, u1);
+  const T ev[3] = {wp2 * e[0], wp2 * e[1], wp2 * e[2]}, ew[3] = {wr2 * e[3], wr2 * e[4], wr2 * e[5]};
   if (s < 3) {
     out[s] = wp2 * uu;                                   // LL(s,s)
     out[3 + s] = wp2 * uu1;                              // LL(s,s+1)
@@ -1319,8 +1349,14 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
       for (;;) {
         // ---- per-task 6x6 blocks ----
         GMR_DUP(3) if (is_task) {
-          if (quad) task_block_quad(ts, e, jl_kap, jl_bet, t_rs, t_xb, t_wp, t_wr, Bt + kBT * tl);
-          else task_block(t_body, xpos, xquat, e, jl_kap, jl_bet, t_wp, t_wr, Bt + kBT * tl);
+          if (quad) task_block_quad<blk_t>(ts, e, jl_kap, jl_bet, t_rs, t_xb, t_wp, t_wr, reinterpret_cast<blk_t *>(Bt + kBT * tl));
+          else {
+#if GMR_IK_MIXED
+            __builtin_trap();  // (the mixed-precision experiment covers the three-lanes-per-task path only: <= 16 tasks)
+#else
+            task_block(t_body, xpos, xquat, e, jl_kap, jl_bet, t_wp, t_wr, Bt + kBT * tl);
+#endif
+          }
         }
         const double diag = ik_args(Lk)->prm.damping + ik_args(Lk)->prm.lm_damping * sum_mu;
         const double lgain_generic = SQ ? 0.0 : ik_args(Lk)->prm.limit_gain;  // (read here, in uniform control flow)
@@ -1349,8 +1385,11 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
           cross(xb, ax, mo);
 #pragma unroll
           for (int i = 0; i < 3; i++) { Si[i] = is_trans ? a_axis[i] : mo[i]; Si[3 + i] = is_trans ? 0.0 : ax[i]; }
+          {
+            blk_t *So = reinterpret_cast<blk_t *>(S + 6 * lane);  // (mixed: the first half of the dof's 48-byte slot)
 #pragma unroll
-          for (int k = 0; k < 6; k++) S[6 * lane + k] = Si[k];
+            for (int k = 0; k < 6; k++) So[k] = (blk_t)Si[k];
+          }
         }
         __syncthreads();
         GMR_STAMP(4);
@@ -1360,6 +1399,20 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
                       // composite.  A quarter's plan entry is four source block offsets (absent ones point at the zero block) and a
                       // destination; no masks, no selects.  Same wave, so LDS program order makes a pass see the previous one's
                       // writes without a barrier.
+#if GMR_IK_MIXED
+          if (__builtin_amdgcn_inverse_ballot_w64(kmask<0x007f007fu>())) {  // (lane & 15) < 7: 28 floats of a block, four per lane
+            char *lb = reinterpret_cast<char *>(lds);
+            auto pass = [&](unsigned s0, unsigned s1, unsigned s2, unsigned s3, unsigned dst) {
+              const float4 v0 = *reinterpret_cast<const float4 *>(lb + s0), v1 = *reinterpret_cast<const float4 *>(lb + s1);
+              const float4 v2 = *reinterpret_cast<const float4 *>(lb + s2), v3 = *reinterpret_cast<const float4 *>(lb + s3);
+              float4 sum;
+              sum.x = (v0.x + v1.x) + (v2.x + v3.x);
+              sum.y = (v0.y + v1.y) + (v2.y + v3.y);
+              sum.z = (v0.z + v1.z) + (v2.z + v3.z);
+              sum.w = (v0.w + v1.w) + (v2.w + v3.w);
+              *reinterpret_cast<float4 *>(lb + dst) = sum;
+            };
+#else
           if (__builtin_amdgcn_inverse_ballot_w64(kmask<0x3fff3fffu>())) {  // (lane & 15) < kBTLanes
             char *lb = reinterpret_cast<char *>(lds);
             auto pass = [&](unsigned s0, unsigned s1, unsigned s2, unsigned s3, unsigned dst) {
@@ -1370,6 +1423,7 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
               sum.y = (v0.y + v1.y) + (v2.y + v3.y);
               *reinterpret_cast<double2 *>(lb + dst) = sum;
             };
+#endif
             // the first kCompRegs passes run from addresses resolved at the stage's entry (no plan read, no unpacking)
 #pragma unroll
             for (int p = 0; p < kCompRegs; ++p)
@@ -1384,6 +1438,24 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
         GMR_STAMP(5);
         double ci = 0.0, lo = -1e30, hi = 1e30, hdiag = 0.0;  // hdiag: S_i . F_i, the undamped diagonal of H
         GMR_DUP(6) if (real_row) {
+#if GMR_IK_MIXED
+          float B[28], Sf[6], Fi[6];  // the composite block in float32: seven 16-byte reads
+#pragma unroll
+          for (int c = 0; c < 7; c++) {
+            const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Bt + kBT * a_comp) + 16 * c);
+            B[4 * c] = v.x; B[4 * c + 1] = v.y; B[4 * c + 2] = v.z; B[4 * c + 3] = v.w;
+          }
+#pragma unroll
+          for (int k = 0; k < 6; k++) Sf[k] = (float)Si[k];
+          sym6_mul<float>(B, Sf, Sf + 3, Fi, Fi + 3);
+          hdiag = (double)(Sf[0] * Fi[0] + Sf[1] * Fi[1] + Sf[2] * Fi[2] + Sf[3] * Fi[3] + Sf[4] * Fi[4] + Sf[5] * Fi[5]);
+          {
+            float *Fo = reinterpret_cast<float *>(F + 6 * lane);
+#pragma unroll
+            for (int k = 0; k < 6; k++) Fo[k] = Fi[k];
+          }
+          ci = (double)(Sf[0] * B[21] + Sf[1] * B[22] + Sf[2] * B[23] + Sf[3] * B[24] + Sf[4] * B[25] + Sf[5] * B[26]);
+#else
           double B[kBTLanes * 2];  // the composite block, seven b128 reads per half
 #pragma unroll
           for (int c = 0; c < kBTLanes; c++) {
@@ -1391,11 +1463,12 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
             B[2 * c] = v.x; B[2 * c + 1] = v.y;
           }
           double Fi[6];
-          sym6_mul(B, Si, Si + 3, Fi, Fi + 3);
+          sym6_mul<double>(B, Si, Si + 3, Fi, Fi + 3);
           hdiag = Si[0] * Fi[0] + Si[1] * Fi[1] + Si[2] * Fi[2] + Si[3] * Fi[3] + Si[4] * Fi[4] + Si[5] * Fi[5];
 #pragma unroll
           for (int k = 0; k < 6; k++) F[6 * lane + k] = Fi[k];
           ci = Si[0] * B[21] + Si[1] * B[22] + Si[2] * B[23] + Si[3] * B[24] + Si[4] * B[25] + Si[5] * B[26];
+#endif
           if (!SQ && a_lim) {  // mink ConfigurationLimit: -gain (q - lower) <= dq <= gain (upper - q)
             const double qv = q[a_qadr];
             const int ar = launder(2 * lane);
@@ -1414,6 +1487,21 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
           // times over.  Plans of up to kHPlanRegs rounds (G1: 5) sit in registers for the whole work item; longer ones are read
           // from their LDS copy, one iteration ahead.
           char *lb = reinterpret_cast<char *>(lds);
+#if GMR_IK_MIXED
+          auto two_rounds = [&](const uint2 ca, const uint2 cb) {  // S_j and F_i: six floats each (16 + 8 bytes) from the same slots
+            const char *Sa = lb + (ca.x & 0xffffu), *Fa = lb + (ca.x >> 16), *Sb = lb + (cb.x & 0xffffu), *Fb = lb + (cb.x >> 16);
+            const float4 a0 = *reinterpret_cast<const float4 *>(Sa), f0 = *reinterpret_cast<const float4 *>(Fa);
+            const float2 a1 = *reinterpret_cast<const float2 *>(Sa + 16), f1 = *reinterpret_cast<const float2 *>(Fa + 16);
+            const float4 b0 = *reinterpret_cast<const float4 *>(Sb), g0 = *reinterpret_cast<const float4 *>(Fb);
+            const float2 b1 = *reinterpret_cast<const float2 *>(Sb + 16), g1 = *reinterpret_cast<const float2 *>(Fb + 16);
+            const double da = (double)(a0.x * f0.x + a0.y * f0.y + a0.z * f0.z + a0.w * f0.w + a1.x * f1.x + a1.y * f1.y);
+            const double db = (double)(b0.x * g0.x + b0.y * g0.y + b0.z * g0.z + b0.w * g0.w + b1.x * g1.x + b1.y * g1.y);
+            *reinterpret_cast<double *>(lb + (ca.y & 0xffffu)) = da;
+            *reinterpret_cast<double *>(lb + (ca.y >> 16)) = da;
+            *reinterpret_cast<double *>(lb + (cb.y & 0xffffu)) = db;
+            *reinterpret_cast<double *>(lb + (cb.y >> 16)) = db;
+          };
+#else
           auto two_rounds = [&](const uint2 ca, const uint2 cb) {
             const double2 *Sa = reinterpret_cast<const double2 *>(lb + (ca.x & 0xffffu)), *Fa = reinterpret_cast<const double2 *>(lb + (ca.x >> 16));
             const double2 *Sb = reinterpret_cast<const double2 *>(lb + (cb.x & 0xffffu)), *Fb = reinterpret_cast<const double2 *>(lb + (cb.x >> 16));
@@ -1426,6 +1514,7 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
             *reinterpret_cast<double *>(lb + (cb.y & 0xffffu)) = db;
             *reinterpret_cast<double *>(lb + (cb.y >> 16)) = db;
           };
+#endif
           if (kHPlanRegs > 0 && npairp <= 64 * kHPlanRegs) {  // wave-uniform
 #pragma unroll
             for (int it = 0; it < kHPlanRegs / 2; ++it)
