@@ -891,6 +891,12 @@ __device__ __forceinline__ int box_qp(int lane, int n_act, const double *Hm, dou
 // float64 ALU op that does; checked on the chip, tools/dpp_fmac_probe.hip).  The source lane must be enabled in EXEC (a disabled
 // lane reads as 0).  The compiler does not see a DPP instruction inside inline asm, so the two hazards are covered by hand:
 // NOP2 = the broadcast operand was written by the VALU instruction right before (2 wait states).
+// The hazard cover is hand-placed around code the compiler schedules, so it is tied to the toolchain it was validated on (parity
+// tests + a soak of thousands of bitwise-identical launches, tools/soak.py): ROCm 7.2's clang 22 targeting gfx950.  Another
+// compiler has to repeat that validation; -DGMR_ALLOW_UNVALIDATED_TOOLCHAIN acknowledges it.
+#if !defined(GMR_ALLOW_UNVALIDATED_TOOLCHAIN) && defined(__clang_major__) && (__clang_major__ != 22 || HIP_VERSION_MAJOR != 7)
+#error "fmac_bcast_neg: the DPP hazard cover was validated with ROCm 7.x / clang 22 only (see the comment above); re-run tools/soak.py and tests -m gpu, then build with -DGMR_ALLOW_UNVALIDATED_TOOLCHAIN"
+#endif
 template <int K, bool NOP2 = false>
 __device__ __forceinline__ void fmac_bcast_neg(double &acc, double src, double u) {
   // (volatile: the statement must stay inside the EXEC region it was written in -- the compiler does not know it is a VALU op)
