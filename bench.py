@@ -423,17 +423,21 @@ def main():
         nh = S * T
         hp_all, hq_all = pos[:nh].cpu().numpy(), quat[:nh].cpu().numpy()
         h_offs = offs[: nh // T + 1]
-        t_host, (q_host, _) = timed(lambda: eng.ik_solve_host(hp_all, hq_all, sc, h_offs, want_iters=False), reps=3)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        q_host, _ = eng.ik_solve_host(hp_all, hq_all, sc, h_offs, want_iters=False)   # first call: page-locks its result array
+        t_first = time.perf_counter() - t1
+        t_host, _ = timed(lambda: eng.ik_solve_host(hp_all, hq_all, sc, h_offs, want_iters=False, out=q_host), reps=3)
         same = bool(np.array_equal(q_host, out[:nh].cpu().numpy()))
 
         def serial():
             q_h, _, _ = eng.ik_solve(torch.from_numpy(hp_all[: nh // 4]).to(dev), torch.from_numpy(hq_all[: nh // 4]).to(dev), sc, make_items(h_offs[: nh // 4 // T + 1]), want_iters=False)
             return q_h.cpu().numpy()
         t_ser, _ = timed(serial, reps=2)
-        result["host_fed"] = {"frames": nh, "frames_per_s": nh / t_host, "bitwise_equal_to_resident": same,
+        result["host_fed"] = {"frames": nh, "frames_per_s": nh / t_host, "first_call_frames_per_s": nh / t_first, "bitwise_equal_to_resident": same,
                               "serial_pageable_frames_per_s": (nh // 4) / t_ser,
                               "includes": "pageable host key-points read in place by the copy engine (H2D 392 B/frame) + kernel + D2H of qpos (288 B/frame) into a "
-                                          "pinned host result, batches of >= 2048 clips alternating between two streams; serial_pageable = round 1's "
+                                          "pinned host result (reused across calls; first_call includes page-locking it), batches of >= 2048 clips alternating between two streams; serial_pageable = round 1's "
                                           "copy-in / solve / copy-out into a fresh pageable array, no overlap (a quarter of the frames)"}
         del hp_all, hq_all, q_host
     if rank == 0 and world == 1 and not args.no_cpu and not args.hot_only:

@@ -133,7 +133,8 @@ class Engine:
         return out, iters, qfin
 
     def ik_solve_host(self, pos: np.ndarray, quat: np.ndarray, slot_col: np.ndarray, seq_offsets, params: Optional[IKParams] = None,
-                      height_scales=None, min_batch_clips: int = 2048, max_batches: int = 4, want_iters: bool = True, check: bool = True):
+                      height_scales=None, min_batch_clips: int = 2048, max_batches: int = 4, want_iters: bool = True, check: bool = True,
+                      out: Optional[np.ndarray] = None):
         """Whole clips from HOST arrays to a HOST result, pipelined: what the dataset scripts hand over
         (scripts/smplx_to_robot_dataset.py:84-89 builds host key-points per file) without a serial copy-in / solve / copy-out.
 
@@ -144,7 +145,10 @@ class Engine:
         straight into a pinned host result (a fresh pageable result array would cost more in page faults than the kernel takes).
         Results are bitwise those of ``ik_solve`` on resident tensors (same kernel, same per-clip work items).  With ``check``
         every batch is inspected on the device (non-finite qpos -> FloatingPointError, a capped QP -> RuntimeError).  Returns
-        (qpos [N, nq] float64, iters [N] int32 or None) as numpy arrays backed by pinned memory.  Measured rates: DESIGN.md.
+        (qpos [N, nq] float64, iters [N] int32 or None) as numpy arrays backed by pinned memory.  ``out``: the qpos array of an
+        earlier call of the same size, to be overwritten -- page-locking a fresh multi-GB result costs more than the solve (7 GB:
+        0.7 s), so loops over many batches should hand the previous result back (or simply drop it before the next call: the
+        allocator then reuses its pinned block).  Measured rates: DESIGN.md.
         """
         from .schedule import make_items
         if pos.dtype != quat.dtype or pos.dtype not in (np.float32, np.float64):
@@ -158,7 +162,14 @@ class Engine:
         slot_col = np.ascontiguousarray(slot_col, dtype=np.int32)
         tdt = torch.float32 if pos.dtype == np.float32 else torch.float64
         hs = None if height_scales is None else np.asarray(height_scales, dtype=np.float64)
-        out = torch.empty((N, self.nq), dtype=torch.float64, pin_memory=True)
+        if out is not None:
+            if not isinstance(out, np.ndarray) or out.shape != (N, self.nq) or out.dtype != np.float64 or not out.flags.c_contiguous:
+                raise EngineError("out must be a C-contiguous float64 [N, nq] array (the result of an earlier call)")
+            out = torch.from_numpy(out)
+            if not out.is_pinned():
+                raise EngineError("out must be pinned host memory: pass the result of an earlier ik_solve_host call")
+        else:
+            out = torch.empty((N, self.nq), dtype=torch.float64, pin_memory=True)
         iters = torch.empty(N, dtype=torch.int32, pin_memory=True) if want_iters else None
         if N == 0:
             return out.numpy(), (iters.numpy() if want_iters else None)

@@ -631,6 +631,11 @@ def test_host_pipeline_bitwise_equals_resident_path():
     for min_clips, max_b in ((1, 4), (2, 3), (1000, 4)):                     # 4 batches, 3 batches, one batch
         q, it = eng.ik_solve_host(pos, quat, sc, offs, height_scales=hs, min_batch_clips=min_clips, max_batches=max_b)
         assert np.array_equal(q, q_res.cpu().numpy()) and np.array_equal(it, it_res.cpu().numpy())
+    q[:] = 0.0
+    q_again, _ = eng.ik_solve_host(pos, quat, sc, offs, height_scales=hs, out=q)   # the previous (pinned) result handed back
+    assert q_again.ctypes.data == q.ctypes.data and np.array_equal(q, q_res.cpu().numpy())
+    with pytest.raises(Exception):
+        eng.ik_solve_host(pos, quat, sc, offs, out=np.zeros_like(q))               # pageable memory is refused
     g = GMR("smplx", "unitree_g1")
     g.HOST_PIPELINE_MIN_FRAMES = 1
     q2 = g.retarget_batch(pos, quat, names, seq_offsets=offs, human_heights=hs * cm.config.human_height_assumption)
