@@ -53,7 +53,14 @@ def motions_from_qpos(gmr: GeneralMotionRetargeting, qpos: torch.Tensor, seq_off
         first[torch.from_numpy(nonempty).to(qpos.device)] = root_pos[torch.from_numpy(offs[:-1][nonempty]).to(qpos.device), :2]
         lens = torch.from_numpy(np.diff(offs)).to(qpos.device)
         root_pos[:, :2] = root_pos[:, :2] - torch.repeat_interleave(first, lens, dim=0)
-    rp, rr, dp, lb = root_pos.cpu().numpy(), root_rot.cpu().numpy(), dof_pos.cpu().numpy(), local_body_pos.cpu().numpy()
+    # to the host through pinned arrays, all four copies in flight together: a fresh pageable array costs more in first-touch
+    # page faults than the copy itself, and torch's host allocator hands the pinned blocks back to the next batch once these
+    # arrays are dropped (pickled and released)
+    host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (root_pos, root_rot, dof_pos, local_body_pos)]
+    for h, t in zip(host, (root_pos, root_rot, dof_pos, local_body_pos)):
+        h.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(qpos.device).synchronize()
+    rp, rr, dp, lb = (h.numpy() for h in host)
     names = list(gmr.model.body_names)
     out = []
     for s in range(len(offs) - 1):
