@@ -358,6 +358,7 @@ def main():
             ts = []
             r = None
             for _ in range(reps):
+                r = None  # (release the previous result first: pinned result blocks are then reused instead of page-locked anew)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 r = fn()
@@ -369,10 +370,10 @@ def main():
         # post-processing, to host arrays ready for pickling (pickle / disk excluded)
         nd = min(S, 2048)
         t_dev, _ = timed(lambda: _dataset_device(gmr, dataset, pos[: nd * T], quat[: nd * T], names, offs[: nd + 1]), reps=3)
-        t_all, _ = timed(lambda: dataset.retarget_clips(gmr, pos[: nd * T], quat[: nd * T], names, offs[: nd + 1]), reps=2)
+        t_all, _ = timed(lambda: dataset.retarget_clips(gmr, pos[: nd * T], quat[: nd * T], names, offs[: nd + 1]), reps=3)
         result["dataset_path"] = {"clips": nd, "frames": nd * T, "frames_per_s_device": nd * T / t_dev, "frames_per_s_to_host": nd * T / t_all,
                                   "includes": "ik_kernel + fk_kernel (local_body_pos) + fk min-height + root adjustments; `to_host` adds the D2H of "
-                                              "root_pos / root_rot / dof_pos (f64) + local_body_pos (f32, 456 B/frame) into pageable arrays"}
+                                              "root_pos / root_rot / dof_pos (f64) + local_body_pos (f32, 456 B/frame) into pinned host arrays and the per-clip dicts"}
         # BASELINE config 2 taken literally: ONE 3000-frame clip on one GPU, parallel-in-time chunks with verified
         # boundaries (Engine.ik_solve_chunked) vs the same clip solved sequentially by one wavefront; an easy and a hard clip
         sclip = {}
