@@ -216,3 +216,52 @@ def test_bvh_motion_parser_matches_python_float():
     for bad in (b"1 2 3\n4 5\n", b"1 2x 3\n", b"1 - 3\n", b"1 2 3 4 5 6 7 8 9\n" * 2):
         cap = 8 if bad.startswith(b"1 2 3 4") else len(out)
         assert lib.gmr_bvh_parse_motion(bad, len(bad), 10, out.ctypes.data, cap, C.byref(nl), C.byref(nc)) == -1
+
+
+def test_bvh_header_tokenizer_grammar(tmp_path):
+    """gmr_bvh_parse_header (gmr_amd/csrc/bvh_text.h): the token grammar accepts any line structure, keeps the reference's file
+    semantics (joint order, End Sites ignored, Euler order from the first joint's last three channels, `\\w+` names) and rejects
+    what it cannot lay out -- including truncated and garbage input."""
+    from gmr_amd.bvh import read_bvh, _parse_header
+    one_line = ("HIERARCHY ROOT Hips { OFFSET 0 1.5 -2e-1 CHANNELS 6 Xposition Yposition Zposition Zrotation Yrotation Xrotation "
+                "JOINT mixamorig:Spine { OFFSET 0 10 0 CHANNELS 3 Zrotation Yrotation Xrotation End Site { OFFSET 0 5 0 } } "
+                "JOINT Leg_L { OFFSET 1 0 0 CHANNELS 3 Zrotation Yrotation Xrotation JOINT Foot { OFFSET 0 -40 0 CHANNELS 3 Zrotation Yrotation Xrotation "
+                "End Site { OFFSET 0 0 10 } } } } MOTION Frames: 2 Frame Time: 0.0333333\n"
+                "1 2 3 10 20 30 1 2 3 4 5 6 7 8 9\n-1 -2 -3 0 0 0 0 0 0 0 0 0 0 0 0\n")
+    p = tmp_path / "one_line.bvh"
+    p.write_text(one_line)
+    names, parents, offsets, chan, order, fnum, ftime, moff = _parse_header(p.read_bytes(), str(p))
+    assert names == ["Hips", "mixamorig", "Leg_L", "Foot"] and list(parents) == [-1, 0, 0, 2]      # `\\w+` capture, End Sites skipped
+    assert list(chan) == [6, 3, 3, 3] and order == (2, 1, 0) and fnum == 2 and abs(ftime - 0.0333333) < 1e-12
+    np.testing.assert_array_equal(offsets, [[0, 1.5, -0.2], [0, 10, 0], [1, 0, 0], [0, -40, 0]])
+    assert p.read_bytes()[moff:moff + 5] == b"1 2 3"
+    a = read_bvh(str(p))
+    assert a.pos.shape == (2, 4, 3) and np.array_equal(a.pos[1, 0], [-1, -2, -3]) and np.array_equal(a.eulers_deg[0, 3], [7, 8, 9])
+    xyz = one_line.replace("Zrotation Yrotation Xrotation JOINT mixamorig", "Xrotation Yrotation Zrotation JOINT mixamorig", 1)
+    p.write_text(xyz)
+    assert read_bvh(str(p)).order == (0, 1, 2)                                                       # Euler order follows the first joint
+    bad_cases = {
+        "truncated": one_line[:200],
+        "no hierarchy": one_line.replace("HIERARCHY", "HIERARCHIE"),
+        "unbalanced": one_line.replace("} } } } MOTION", "} } } MOTION"),
+        "bad offset": one_line.replace("OFFSET 0 10 0", "OFFSET 0 ten 0"),
+        "bad channel": one_line.replace("Zrotation Yrotation Xrotation JOINT Foot", "Zrotation Yrotation Wrotation JOINT Foot"),
+        "root without rotations": one_line.replace("CHANNELS 6 Xposition Yposition Zposition Zrotation Yrotation Xrotation", "CHANNELS 3 Xposition Yposition Zposition"),
+        "no frame time": one_line.replace("Frame Time:", "FrameTime:"),
+        "binary": "\x00\x01\x02 HIERARCHY",
+    }
+    for label, text in bad_cases.items():
+        p.write_text(text)
+        with pytest.raises((ValueError, NotImplementedError)):
+            read_bvh(str(p))
+    nine = one_line.replace("CHANNELS 3 Zrotation Yrotation Xrotation JOINT Foot", "CHANNELS 9 Xposition Yposition Zposition Zrotation Yrotation Xrotation Xposition Yposition Zposition JOINT Foot")
+    p.write_text(nine)
+    with pytest.raises(NotImplementedError):                                                         # mixed / 9-channel joints: rejected, not mis-read
+        read_bvh(str(p))
+    # many joints: the name / joint capacity grows
+    deep = "HIERARCHY ROOT j0 { OFFSET 0 0 0 CHANNELS 6 Xposition Yposition Zposition Zrotation Yrotation Xrotation " + \
+        "".join(f"JOINT j{i} {{ OFFSET 0 1 0 CHANNELS 3 Zrotation Yrotation Xrotation " for i in range(1, 200)) + "End Site { OFFSET 0 1 0 } " + "} " * 200 + \
+        "MOTION\nFrames: 1\nFrame Time: 0.01\n" + " ".join(["0"] * (3 + 3 * 200)) + "\n"
+    p.write_text(deep)
+    a = read_bvh(str(p))
+    assert len(a.bones) == 200 and a.bones[199] == "j199" and list(a.parents[:3]) == [-1, 0, 1]
