@@ -371,7 +371,22 @@ def main():
         nd = min(S, 2048)
         t_dev, _ = timed(lambda: _dataset_device(gmr, dataset, pos[: nd * T], quat[: nd * T], names, offs[: nd + 1]), reps=3)
         t_all, _ = timed(lambda: dataset.retarget_clips(gmr, pos[: nd * T], quat[: nd * T], names, offs[: nd + 1]), reps=3)
+        # ... and all the way from host key-points to pickle files (the scripts' whole process_file body but the SMPL-X forward pass):
+        # numpy in -> retarget_clips -> one pickle per clip on tmpfs; 256 clips
+        import shutil
+        import tempfile
+        npk = min(nd, 256)
+        hp_d, hq_d = pos[: npk * T].cpu().numpy(), quat[: npk * T].cpu().numpy()
+        tmpd = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+
+        def to_pickles():
+            motions = dataset.retarget_clips(gmr, hp_d, hq_d, names, offs[: npk + 1])
+            for i, mo in enumerate(motions):
+                dataset.save_motion(os.path.join(tmpd, f"{i}.pkl"), mo, override=True)
+        t_pk, _ = timed(to_pickles, reps=2)
+        shutil.rmtree(tmpd, ignore_errors=True)
         result["dataset_path"] = {"clips": nd, "frames": nd * T, "frames_per_s_device": nd * T / t_dev, "frames_per_s_to_host": nd * T / t_all,
+                                  "frames_per_s_host_keypoints_to_pickles": npk * T / t_pk, "pickle_clips": npk,
                                   "includes": "ik_kernel + fk_kernel (local_body_pos) + fk min-height + root adjustments; `to_host` adds the D2H of "
                                               "root_pos / root_rot / dof_pos (f64) + local_body_pos (f32, 456 B/frame) into pinned host arrays and the per-clip dicts"}
         # BASELINE config 2 taken literally: ONE 3000-frame clip on one GPU, parallel-in-time chunks with verified
