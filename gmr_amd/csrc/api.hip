@@ -7,7 +7,6 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <array>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -764,85 +763,6 @@ int build_device_model(gmr_model *m) {
     for (int i = 0; i < 4; ++i) r.lrot[i] = lrot[4 * b + i];
   }
   const size_t o_fkbody = P.add(fkbody);
-  // ---- two-track schedule of the same tree (fk_pos2_kernel): steps of two mutually independent bodies.  Greedy list scheduling:
-  //      each track prefers to continue the chain it holds in registers, otherwise takes the ready body with the longest chain
-  //      below it; a body whose parent is not in its track's registers fetches it from an LDS slot, planned by lifetime.
-  std::vector<gmr::FkBody> fksteps;
-  int fk_nsteps = 0, fk_nslots2 = 0, fk_root_slot2 = -1, fk_dof_chunks = 0;
-  {
-    std::vector<int> height(nb, 0), size(nb, 1), step_of(nb, -1);
-    for (int b = nb - 1; b > 0; --b) { height[parent[b]] = std::max(height[parent[b]], height[b] + 1); size[parent[b]] += size[b]; }
-    std::vector<char> sched(nb, 0), done(nb, 0);
-    sched[0] = done[0] = 1;
-    int last[2] = {0, 0}, left = nb - 1;
-    std::vector<std::array<int, 2>> steps;
-    while (left > 0) {
-      std::array<int, 2> pick = {-1, -1};
-      for (int tr = 0; tr < 2; ++tr) {
-        int best = -1;
-        std::array<int, 4> bkey = {0, 0, 0, 0};
-        for (int c = 1; c < nb; ++c) {
-          if (sched[c] || c == pick[0] || !done[parent[c]]) continue;
-          const std::array<int, 4> key = {parent[c] == last[tr] ? 1 : 0, height[c], size[c], -c};
-          if (best < 0 || key > bkey) { best = c; bkey = key; }
-        }
-        pick[tr] = best;
-      }
-      for (int tr = 0; tr < 2; ++tr)
-        if (pick[tr] >= 0) { sched[pick[tr]] = 1; --left; step_of[pick[tr]] = (int)steps.size(); }
-      steps.push_back(pick);
-      for (int tr = 0; tr < 2; ++tr)
-        if (pick[tr] >= 0) { done[pick[tr]] = 1; last[tr] = pick[tr]; }
-    }
-    fk_nsteps = (int)steps.size();
-    // which bodies fetch their parent from a slot, and the slot lifetimes [step the parent is computed, last step that reads it]
-    std::vector<int> fetch(nb, 0), lo(nb, 0), hi(nb, -2), slot2(nb, -1);
-    int lt[2] = {0, 0};
-    for (int s2 = 0; s2 < fk_nsteps; ++s2)
-      for (int tr = 0; tr < 2; ++tr) {
-        const int c = steps[s2][tr];
-        if (c < 0) continue;
-        if (parent[c] != lt[tr]) { fetch[c] = 1; const int p2 = parent[c]; lo[p2] = step_of[p2]; hi[p2] = std::max(hi[p2], s2); }
-        lt[tr] = c;
-      }
-    std::vector<int> order2;
-    for (int b = 0; b < nb; ++b) if (hi[b] > -2) order2.push_back(b);
-    std::sort(order2.begin(), order2.end(), [&](int x, int y) { return lo[x] < lo[y] || (lo[x] == lo[y] && x < y); });
-    std::vector<int> free_at;  // last reading step of the slot's current tenant (a read at step s precedes a save at step s)
-    for (int b : order2) {
-      int k = -1;
-      for (int i = 0; i < (int)free_at.size() && k < 0; ++i) if (free_at[i] <= lo[b]) k = i;
-      if (k < 0) { k = (int)free_at.size(); free_at.push_back(0); }
-      free_at[k] = hi[b];
-      slot2[b] = k;
-    }
-    fk_nslots2 = (int)free_at.size();
-    fk_root_slot2 = slot2[0];
-    // dof registers: chunk c holds row[4c .. 4c+3], the last chunk is shifted back to end at the row's end
-    const int ndof = nq - 7;
-    fk_dof_chunks = (ndof + 3) / 4;
-    auto dof_reg = [&](int di) {
-      if (ndof < 4) return di;
-      const int last_start = ndof - 4, c = std::min(di / 4, fk_dof_chunks - 1);
-      const int st = std::min(4 * c, last_start);
-      return di >= st && di < st + 4 ? 4 * c + (di - st) : 4 * (fk_dof_chunks - 1) + (di - last_start);
-    };
-    fksteps.assign((size_t)2 * std::max(fk_nsteps, 1), gmr::FkBody{});
-    for (int s2 = 0; s2 < std::max(fk_nsteps, 1); ++s2)
-      for (int tr = 0; tr < 2; ++tr) {
-        gmr::FkBody &r = fksteps[2 * s2 + tr];
-        r.src_slot = -1; r.dofidx = -1; r.save_slot = -1; r.out = -1;
-        r.lrot[3] = 1.0f; r.axis[2] = 1.0;  // an idle record: identity transform (never committed)
-        const int c = s2 < fk_nsteps ? steps[s2][tr] : -1;
-        if (c < 0) continue;
-        r = fkbody[c];
-        r.out = c;
-        r.src_slot = fetch[c] ? slot2[parent[c]] : -1;
-        r.save_slot = slot2[c];
-        r.dofidx = dofidx[c] >= 0 ? dof_reg(dofidx[c]) : -1;
-      }
-  }
-  const size_t o_fksteps = P.add(fksteps);
 
   HIP_TRY(m, hipMalloc(&m->dev, P.buf.size()));
   m->dev_bytes = P.buf.size();
@@ -852,8 +772,7 @@ int build_device_model(gmr_model *m) {
   m->dm_eval_dev = DP(gmr::DevModel, o_dm_eval);
   gmr::FkTree &fk = m->fk;
   fk.parent = DP(int, o_parent); fk.dofidx = DP(int, o_dofidx); fk.src_slot = DP(int, o_src); fk.save_slot = DP(int, o_save);
-  fk.lpos = DP(float, o_lpos); fk.lrot = DP(float, o_lrot); fk.jaxis = DP(float, o_jaxis); fk.jaxis64 = DP(double, o_jaxis64); fk.body = DP(gmr::FkBody, o_fkbody); fk.steps = DP(gmr::FkBody, o_fksteps);
-  fk.nsteps = fk_nsteps; fk.nslots2 = std::max(1, fk_nslots2); fk.dof_chunks = fk_dof_chunks; fk.pad_ = fk_root_slot2;
+  fk.lpos = DP(float, o_lpos); fk.lrot = DP(float, o_lrot); fk.jaxis = DP(float, o_jaxis); fk.jaxis64 = DP(double, o_jaxis64); fk.body = DP(gmr::FkBody, o_fkbody);
   fk.nbody = nb; fk.ndof = nq - 7; fk.nslots = nslots;
   fk.dof_in_order = 1;
   for (int b = 0, prev = -1; b < nb; ++b)
@@ -931,7 +850,7 @@ static gmr_model *model_create_impl(const void *blob, size_t blob_bytes, int dev
   if (const char *e = getenv("GMR_AMD_GENERIC_QP")) m->force_generic = e[0] == '1';
   if (force_generic) m->force_generic = true;
   m->min_nvp = min_nvp;
-  if (const char *e = getenv("GMR_AMD_FK_PARTS")) m->fk_pos_parts = e[0] == '0' ? 0 : e[0] == '2' ? 2 : e[0] == '3' ? 3 : 1;
+  if (const char *e = getenv("GMR_AMD_FK_PARTS")) m->fk_pos_parts = e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1;
   if (build_device_model(m) != GMR_OK) return fail(m, "model build failed");
   return m;
 }
@@ -1292,23 +1211,10 @@ int gmr_fk(gmr_model *m, const float *root_pos, const float *root_rot_xyzw, cons
   const int64_t nblk = (n_frames + gmr::kFkThreads - 1) / gmr::kFkThreads;
   if (nblk > 0x7fffffff) { set_err(m, "too many frames for one launch"); return GMR_EINVAL; }
   // the rotation stage is the last LDS region: a positions-only call does not allocate it (more workgroups per CU)
-  if (!body_rot_out && m->fk_pos_parts == 3 && m->h.nq - 7 >= 4 && m->h.nq - 7 <= 64) {  // positions, two bodies per step (fk_pos2_kernel)
-    const int64_t nw = (n_frames + gmr::kFkWave - 1) / gmr::kFkWave;
-    if (nw > 0x7fffffff) { set_err(m, "too many frames for one launch"); return GMR_EINVAL; }
-    const int lds = (m->fk.nslots2 * 7 + 3 * m->fk.nbody) * gmr::kFkWave * (int)sizeof(float);
-    if (m->h.nq - 7 <= 32)
-      hipLaunchKernelGGL((gmr::fk_pos2_kernel<32>), dim3((unsigned)nw), dim3(gmr::kFkWave), lds, static_cast<hipStream_t>(stream), m->fk, root_pos,
-                         root_rot_xyzw, dof, n_frames, body_pos_out);
-    else
-      hipLaunchKernelGGL((gmr::fk_pos2_kernel<64>), dim3((unsigned)nw), dim3(gmr::kFkWave), lds, static_cast<hipStream_t>(stream), m->fk, root_pos,
-                         root_rot_xyzw, dof, n_frames, body_pos_out);
-    HIP_TRY(m, hipGetLastError());
-    return GMR_OK;
-  }
   if (!body_rot_out && m->fk_pos_parts > 0) {  // positions only: one wavefront per tile, the whole tile image in LDS (fk_pos_kernel)
     const int64_t nw = (n_frames + gmr::kFkWave - 1) / gmr::kFkWave;
     if (nw > 0x7fffffff) { set_err(m, "too many frames for one launch"); return GMR_EINVAL; }
-    const int nb = m->fk.nbody, parts = m->fk_pos_parts == 3 ? 1 : m->fk_pos_parts, prow = parts == 1 ? 3 * nb : 3 * ((nb + parts - 1) / parts);
+    const int nb = m->fk.nbody, parts = m->fk_pos_parts, prow = parts == 1 ? 3 * nb : 3 * ((nb + parts - 1) / parts);
     const int lds = (std::max(1, m->fk.nslots) * 7 + prow) * gmr::kFkWave * (int)sizeof(float);
     if (parts == 1)
       hipLaunchKernelGGL((gmr::fk_pos_kernel<1>), dim3((unsigned)nw), dim3(gmr::kFkWave), lds, static_cast<hipStream_t>(stream), m->fk, root_pos,

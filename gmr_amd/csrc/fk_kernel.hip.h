@@ -40,8 +40,7 @@ constexpr int kFkMaxSlots = 12;
 // Everything the chain needs about one body, in one 80-byte record: read with two scalar loads (s_load_dwordx16 + x4) and
 // fetched one body ahead of its use, instead of a dozen dependent scalar loads per body in front of the wave-uniform branches.
 struct FkBody {
-  int src_slot, dofidx, save_slot, out;   // src_slot: -1 = the previous body is the parent; dofidx: -1 = no hinge; out: two-track
-                                          // schedule only -- the body this record computes (-1: idle), dofidx then = dof register
+  int src_slot, dofidx, save_slot, pad0;  // src_slot: -1 = the previous body is the parent; dofidx: -1 = no hinge
   float lpos[3], pad1;                    // local translation
   float lrot[4];                          // local rotation xyzw, raw XML values (not normalised)
   double axis[3], pad2;                   // unit hinge axis in float64 (torch promotes the hinge quaternion to float64)
@@ -55,8 +54,6 @@ struct FkTree {     // device arrays, [nbody]
   const float *jaxis;  // [nb][3] hinge axis, unit (double normalised, then rounded)
   const double *jaxis64;  // [nb][3] unit axis in float64 (torch promotes the hinge quaternion to float64)
   const FkBody *body;     // [nb] the same, one record per body (what the kernels read)
-  const FkBody *steps;    // [2 * nsteps] two-track schedule (fk_pos2_kernel): records 2s and 2s+1 are computed together
-  int nsteps, nslots2, dof_chunks, pad_;  // dof_chunks: 16-byte loads that bring a frame's dof row into registers
   int nbody, ndof, nslots, dof_in_order;  // dof_in_order: dofidx never decreases along the bodies (the register window needs it)
 };
 
@@ -118,21 +115,20 @@ __device__ __forceinline__ void fk_hinge_quat(const double ax[3], float ang, flo
 }
 
 // One body record through the constant address space (scalar loads).
-__device__ __forceinline__ FkBody fk_record(const FkBody *arr, int j) {
+__device__ __forceinline__ FkBody fk_body(const FkTree &t, int j) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  const auto *p = reinterpret_cast<const FkBody __attribute__((address_space(4))) *>(reinterpret_cast<uintptr_t>(arr)) + j;
+  const auto *p = reinterpret_cast<const FkBody __attribute__((address_space(4))) *>(reinterpret_cast<uintptr_t>(t.body)) + j;
   FkBody r;
-  r.src_slot = p->src_slot; r.dofidx = p->dofidx; r.save_slot = p->save_slot; r.out = p->out; r.pad1 = 0.f; r.pad2 = 0.0;
+  r.src_slot = p->src_slot; r.dofidx = p->dofidx; r.save_slot = p->save_slot; r.pad0 = 0; r.pad1 = 0.f; r.pad2 = 0.0;
 #pragma unroll
   for (int i = 0; i < 3; i++) { r.lpos[i] = p->lpos[i]; r.axis[i] = p->axis[i]; }
 #pragma unroll
   for (int i = 0; i < 4; i++) r.lrot[i] = p->lrot[i];
   return r;
 #else
-  return arr[j];
+  return t.body[j];
 #endif
 }
-__device__ __forceinline__ FkBody fk_body(const FkTree &t, int j) { return fk_record(t.body, j); }
 
 template <int MODE>
 __global__ void __launch_bounds__(kFkThreads) fk_kernel(FkTree t, const float *__restrict__ root_pos,
@@ -417,130 +413,6 @@ __global__ void __launch_bounds__(kFkWave) fk_pos_kernel(FkTree t, const float *
   {
     const int j0 = PARTS == 1 ? 0 : (nbody - 1) / hb * hb;
     flush_part(j0, nbody - j0);
-  }
-}
-
-// ------------------------------------------------------------------ positions only, two bodies per step
-// fk_pos_kernel is bound by VALU issue at the 5 wavefronts per CU its tile image leaves room for (profiles/r02_fk_experiments.md):
-// one wavefront alone keeps a SIMD ~40 % busy, because a body's chain is one long dependency.  A frame has more parallelism than
-// that -- legs and arms are independent sub-chains -- so this kernel walks the tree on TWO tracks: the host schedules the bodies
-// into steps of two mutually independent bodies (gmr_model_create: greedy list scheduling by remaining chain length, chains
-// continue in a track's registers, everything else goes through the planned LDS slots), and the lane computes both in one
-// straight-line block, two independent instruction streams for the scheduler to interleave.  Same arithmetic per body as
-// fk_kernel / fk_pos_kernel (identical results); G1: 19 steps for 37 bodies, 2 slots.  The dof row of the lane's frame is read
-// once into a register vector (8 loads of 16 bytes) and indexed with the step's wave-uniform register number.
-template <int NDOF_REGS>
-__global__ void __launch_bounds__(kFkWave) fk_pos2_kernel(FkTree t, const float *__restrict__ root_pos, const float *__restrict__ root_rot,
-                                                          const float *__restrict__ dof, int64_t n_frames, float *__restrict__ body_pos) {
-#pragma clang fp contract(off)
-  typedef float dofvec __attribute__((ext_vector_type(NDOF_REGS)));
-  extern __shared__ float fk_lds[];
-  const int lane = threadIdx.x;
-  const int nbody = t.nbody, ndof = t.ndof, row = 3 * nbody;
-  const int64_t f0 = (int64_t)blockIdx.x * kFkWave;
-  const int nfb = (int)(n_frames - f0 < kFkWave ? n_frames - f0 : kFkWave);
-  const int64_t fc = lane < nfb ? f0 + lane : n_frames - 1;
-  float *slots = fk_lds;
-  float *img = slots + (size_t)t.nslots2 * 7 * kFkWave;
-  // the dof row -> registers: chunk c covers row[4c .. 4c+3], the last one is shifted back to end at the row's end (the host
-  // numbers the registers accordingly)
-  dofvec dv = 0.f;
-  {
-    const float *myrow = dof + fc * ndof;
-    const int last_start = ndof - 4;
-#pragma unroll
-    for (int c = 0; c < NDOF_REGS / 4; ++c) {
-      if (c < t.dof_chunks) {  // wave-uniform
-        const int st = 4 * c < last_start ? 4 * c : last_start;
-        const FkD4 v = *reinterpret_cast<const FkD4 *>(myrow + st);
-        dv[4 * c] = v.v[0]; dv[4 * c + 1] = v.v[1]; dv[4 * c + 2] = v.v[2]; dv[4 * c + 3] = v.v[3];
-      }
-    }
-  }
-  float cpA[3], crA[4], cpB[3], crB[4];
-#pragma unroll
-  for (int i = 0; i < 3; i++) cpA[i] = cpB[i] = root_pos[fc * 3 + i];
-#pragma unroll
-  for (int i = 0; i < 4; i++) crA[i] = crB[i] = root_rot[fc * 4 + i];
-  {
-    const FkBody r0 = fk_record(t.body, 0);  // (only its save slot matters here: two-track plans keep theirs in steps[])
-    (void)r0;
-  }
-#pragma unroll
-  for (int i = 0; i < 3; i++) img[lane * row + i] = cpA[i];
-  auto save = [&](int sv, const float p[3], const float r[4]) {
-    float *sl = slots + (size_t)sv * 7 * kFkWave + lane;
-#pragma unroll
-    for (int i = 0; i < 3; i++) sl[i * kFkWave] = p[i];
-#pragma unroll
-    for (int i = 0; i < 4; i++) sl[(3 + i) * kFkWave] = r[i];
-  };
-  if (t.pad_ >= 0) save(t.pad_, cpA, crA);  // pad_: slot that keeps the root pose for later fetches, or -1
-  FkBody nA = fk_record(t.steps, 0), nB = fk_record(t.steps, 1);
-  for (int s_ = 0; s_ < t.nsteps; ++s_) {
-    const FkBody a = nA, b = nB;
-    const int nx = s_ + 1 < t.nsteps ? s_ + 1 : s_;
-    nA = fk_record(t.steps, 2 * nx);
-    nB = fk_record(t.steps, 2 * nx + 1);
-    // ---- parents and angles (wave-uniform branches, little work)
-    float ppA[3], prA[4], ppB[3], prB[4];
-    auto parent = [&](const FkBody &r, const float cp[3], const float cr[4], float pp[3], float pr[4]) {
-      if (r.src_slot < 0) {
-#pragma unroll
-        for (int i = 0; i < 3; i++) pp[i] = cp[i];
-#pragma unroll
-        for (int i = 0; i < 4; i++) pr[i] = cr[i];
-      } else {
-        const float *sl = slots + (size_t)r.src_slot * 7 * kFkWave + lane;
-#pragma unroll
-        for (int i = 0; i < 3; i++) pp[i] = sl[i * kFkWave];
-#pragma unroll
-        for (int i = 0; i < 4; i++) pr[i] = sl[(3 + i) * kFkWave];
-      }
-    };
-    parent(a, cpA, crA, ppA, prA);
-    parent(b, cpB, crB, ppB, prB);
-    const float angA = a.dofidx >= 0 ? dv[a.dofidx] : 0.f, angB = b.dofidx >= 0 ? dv[b.dofidx] : 0.f;
-    // ---- both bodies, one straight-line block
-    float jqA[4] = {0.f, 0.f, 0.f, 1.f}, jqB[4] = {0.f, 0.f, 0.f, 1.f};
-    if (a.dofidx >= 0 || b.dofidx >= 0) {  // (a hinge of angle 0 gives exactly the identity, so the idle side may run along)
-      fk_hinge_quat(a.axis, angA, jqA);
-      fk_hinge_quat(b.axis, angB, jqB);
-      if (a.dofidx < 0) { jqA[0] = jqA[1] = jqA[2] = 0.f; jqA[3] = 1.f; }
-      if (b.dofidx < 0) { jqB[0] = jqB[1] = jqB[2] = 0.f; jqB[3] = 1.f; }
-    }
-    float wtA[3], tmA[4], nrA[4], wtB[3], tmB[4], nrB[4], npA[3], npB[3];
-    fk_quat_rotate(prA, a.lpos, wtA);
-    fk_quat_rotate(prB, b.lpos, wtB);
-#pragma unroll
-    for (int i = 0; i < 3; i++) { npA[i] = ppA[i] + wtA[i]; npB[i] = ppB[i] + wtB[i]; }
-    fk_quat_mul(a.lrot, jqA, tmA);
-    fk_quat_mul(b.lrot, jqB, tmB);
-    fk_quat_mul(prA, tmA, nrA);
-    fk_quat_mul(prB, tmB, nrB);
-    // ---- commit
-    if (a.out >= 0) {
-#pragma unroll
-      for (int i = 0; i < 3; i++) { cpA[i] = npA[i]; img[lane * row + 3 * a.out + i] = npA[i]; }
-#pragma unroll
-      for (int i = 0; i < 4; i++) crA[i] = nrA[i];
-      if (a.save_slot >= 0) save(a.save_slot, cpA, crA);
-    }
-    if (b.out >= 0) {
-#pragma unroll
-      for (int i = 0; i < 3; i++) { cpB[i] = npB[i]; img[lane * row + 3 * b.out + i] = npB[i]; }
-#pragma unroll
-      for (int i = 0; i < 4; i++) crB[i] = nrB[i];
-      if (b.save_slot >= 0) save(b.save_slot, cpB, crB);
-    }
-  }
-  __syncthreads();  // (one wavefront: orders the image writes of all lanes before the linear copy)
-  {
-    const int nwords = nfb * row, n4 = nwords >> 2;
-    float *dst = body_pos + f0 * row;
-    for (int i = lane; i < n4; i += kFkWave)
-      *reinterpret_cast<float4 *>(dst + 4 * i) = *reinterpret_cast<const float4 *>(img + 4 * i);
-    for (int i = 4 * n4 + lane; i < nwords; i += kFkWave) dst[i] = img[i];
   }
 }
 
