@@ -399,18 +399,10 @@ constexpr int kBodyC = 11;  // doubles per body in the LDS-staged joint tree: po
 // pointer from memory, and loads through a generic (flat) pointer count as divergent, loads through a global pointer that is not a
 // `restrict` kernel argument as clobberable -- either way every wave-uniform branch, mask and scalar constant derived from the
 // model would be a VMEM load into VGPRs instead of a scalar load.
-#ifndef GMR_IK_MODEL_GENERIC  // (A/B builds only: the model through a generic pointer, as in round 1; no group kernel then)
 using DevModelG = const DevModel __attribute__((address_space(4)));
-#else
-using DevModelG = const DevModel;
-#endif
 // HIP's vector classes cannot be copied out of a qualified address space: read those members through a plain pointer (per-lane data).
 template <class T>
-#ifndef GMR_IK_MODEL_GENERIC
 __device__ __forceinline__ T ld_plain(const T __attribute__((address_space(4))) *p) { return *(const T *)(uintptr_t)p; }
-#else
-__device__ __forceinline__ T ld_plain(const T *p) { return *p; }
-#endif
 
 __device__ __forceinline__ void stage_tree(DevModelG &m, int lane, double *bodyc) {
   if (lane < m.nbody) {
@@ -1655,7 +1647,7 @@ struct IkGroupEntry {
 template <int NVP, bool SQ>
 __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_group_kernel(const IkGroupEntry *__restrict__ entries,
                                                                              const int *__restrict__ block_entry) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(GMR_IK_MODEL_GENERIC)  // (the host pass only needs the kernel's stub; address-space-qualified copies do not parse there)
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass only needs the kernel's stub; address-space-qualified copies do not parse there)
   // (readfirstlane: tell the compiler these are wave-uniform, so that everything derived from them stays in SGPRs)
   const int e = __builtin_amdgcn_readfirstlane(block_entry[blockIdx.x]);
   const uintptr_t ea = (uintptr_t)(entries + e);
