@@ -177,3 +177,22 @@ def test_config5_hands_model_full_size():
     assert torch.equal(q[:block], q[block:2 * block]) and torch.equal(q[:block], q[(S // D - 1) * block:])
     q_ref, it_ref, _ = Oracle(cm.blob).ik_solve(tp[8 * T:8 * T + 150].cpu().numpy(), tq[8 * T:8 * T + 150].cpu().numpy(), sc, make_items([0, 150]))
     assert np.abs(q[8 * T:8 * T + 150].cpu().numpy() - q_ref).max() < 1e-6
+
+
+def test_long_clips_any_heading_chunked_equals_sequential():
+    """Clips that start at ANY heading: some leave the sequential run in a wound-up IK basin for their whole length, so
+    the speculative chunks of those clips verify nowhere and the walk re-solves them -- the chunked result must still be the
+    sequential one, values and solve counts, and clips in the natural basin must verify (few re-solved frames overall is NOT
+    expected here).  Inputs from the GPU generator (synth_clips_torch), bvh_to_g1 config, per-clip heights on top."""
+    cm = compiled("bvh", "unitree_g1")
+    eng = _engine(cm)
+    lens = [700, 450, 900, 600, 820, 510]
+    pos, quat, names, offs = synth.synth_clips_torch(cm, lens, seed=33, device=eng.device, hard=[False, True] * 3, yaw0=np.pi)
+    sc = cm.slot_columns(names)
+    hs = [1.0, 0.95, 1.05, 1.0, 0.9, 1.1]
+    q_seq, it_seq, _ = eng.ik_solve(pos, quat, sc, make_items(offs, height_scales=hs))
+    q_chk, it_chk, info = eng.ik_solve_chunked(pos, quat, sc, offs, chunk=32, burn_in=24, height_scales=hs)
+    assert float((q_chk - q_seq).abs().max().item()) < 1e-6 and torch.equal(it_chk & 0x3FFFFFFF, it_seq & 0x3FFFFFFF)
+    assert 0 <= info["resolved_frames"] <= sum(lens)
+    q_ref, it_ref, _ = Oracle(cm.blob).ik_solve(pos[: lens[0]].cpu().numpy(), quat[: lens[0]].cpu().numpy(), sc, make_items([0, lens[0]], height_scales=hs[:1]))
+    assert np.abs(q_chk[: lens[0]].cpu().numpy() - q_ref).max() < 1e-6 and np.array_equal((it_chk[: lens[0]] & 0x3FFFFFFF).cpu().numpy(), it_ref)
