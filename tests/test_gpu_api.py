@@ -644,3 +644,48 @@ def test_host_pipeline_bitwise_equals_resident_path():
     bad[5, sc[3]] = np.nan
     with pytest.raises(FloatingPointError):
         eng.ik_solve_host(bad, quat, sc, offs)
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """examples/c_abi_retarget.c: the caller loop of scripts/smplx_to_robot_dataset.py:84-112 written against include/gmr_amd.h in
+    C99 -- model from a blob file, hipMalloc'ed buffers, gmr_ik_solve + gmr_fk, no Python or torch in the process -- against the
+    oracle on the same files."""
+    import shutil
+    import subprocess
+    from gmr_amd import _native
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc on this box")
+    _native.load()
+    libdir = os.path.dirname(_native.LIB_PATH)
+    exe = tmp_path / "c_abi_retarget"
+    subprocess.check_call([gcc, "-std=c99", "-D__HIP_PLATFORM_AMD__", f"-I{root}/include", "-I/opt/rocm/include",
+                           os.path.join(root, "examples", "c_abi_retarget.c"), f"-L{libdir}", "-lgmr_amd", "-L/opt/rocm/lib", "-lamdhip64",
+                           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    cm = compiled("smplx", "unitree_g1")
+    lens = [50, 33, 81]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    pos, quat, names, _, _ = synth.synth_clips(cm, 1, int(offs[-1]), seed=23, hard=True, dtype=np.float32, pad_to=20)
+    sc = cm.slot_columns(names)
+    d = tmp_path / "io"
+    d.mkdir()
+    (d / "model.blob").write_bytes(cm.blob)
+    (d / "meta.txt").write_text(f"{offs[-1]} {pos.shape[1]} {cm.nslot} {cm.robot.nq} {cm.robot.nbody} {len(lens)}\n")
+    sc.astype("<i4").tofile(d / "slot_col.i32")
+    offs.astype("<i8").tofile(d / "seq_offsets.i64")
+    pos.astype("<f4").tofile(d / "pos.f32")
+    quat.astype("<f4").tofile(d / "quat.f32")
+    out = subprocess.run([str(exe), str(d)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("ok:"), out.stderr[-2000:] + out.stdout[-500:]
+    q = np.fromfile(d / "qpos.f64", dtype="<f8").reshape(-1, cm.robot.nq)
+    it = np.fromfile(d / "iters.i32", dtype="<i4")
+    bp = np.fromfile(d / "body_pos.f32", dtype="<f4").reshape(-1, cm.robot.nbody, 3)
+    orc = Oracle(cm.blob)
+    q_ref, it_ref, _ = orc.ik_solve(pos, quat, sc, make_items(offs))
+    assert np.abs(q - q_ref).max() < 1e-6 and np.array_equal(it & 0x3FFFFFFF, it_ref)
+    N = q.shape[0]
+    ident = np.zeros((N, 4), np.float32)
+    ident[:, 3] = 1.0
+    bp_ref, _ = orc.fk_kin(np.zeros((N, 3), np.float32), ident, q[:, 7:].astype(np.float32), want_rot=False)
+    assert np.abs(bp - bp_ref).max() < 2e-6

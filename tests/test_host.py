@@ -265,3 +265,28 @@ def test_bvh_header_tokenizer_grammar(tmp_path):
     p.write_text(deep)
     a = read_bvh(str(p))
     assert len(a.bones) == 200 and a.bones[199] == "j199" and list(a.parents[:3]) == [-1, 0, 1]
+
+
+def test_c_abi_headers_are_plain_c_and_the_c_example_links(tmp_path):
+    """include/*.h compile as strict C99 on their own, and examples/c_abi_retarget.c (the boundary used without Python or torch)
+    compiles and links against libgmr_amd.so with nothing but the HIP runtime."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    for hdr in ("gmr_blob.h", "gmr_amd.h"):
+        src = tmp_path / f"use_{hdr}.c"
+        src.write_text(f'#include "{hdr}"\nint main(void) {{ return (int)sizeof(gmr_work_item) - 40; }}\n')
+        subprocess.check_call([gcc, "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", f"-I{root}/include", "-c", str(src), "-o", str(tmp_path / "h.o")])
+    if not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("no ROCm headers")
+    from gmr_amd import _native
+    _native.load()
+    libdir = os.path.dirname(_native.LIB_PATH)
+    exe = tmp_path / "c_abi_retarget"
+    subprocess.check_call([gcc, "-std=c99", "-D__HIP_PLATFORM_AMD__", f"-I{root}/include", "-I/opt/rocm/include",
+                           os.path.join(root, "examples", "c_abi_retarget.c"), f"-L{libdir}", "-lgmr_amd", "-L/opt/rocm/lib", "-lamdhip64",
+                           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    assert exe.exists()
