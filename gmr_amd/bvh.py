@@ -169,3 +169,79 @@ def load_lafan1_file(bvh_file: str, device: int = 0) -> BvhClip:
         last = pos[-1].cpu().numpy()
         height = _estimate_height({n: last[i] for i, n in enumerate(names)})
     return BvhClip(pos, quat, names, height, anim.frametime)
+
+
+class BvhBatch:
+    """Several BVH clips on the GPU as one batch: ``pos [N, B, 3]``, ``quat [N, B, 4]`` (concatenated clips), ``seq_offsets``,
+    one height estimate per clip -- the arguments ``retarget_batch(..., seq_offsets=..., human_heights=...)`` takes."""
+
+    def __init__(self, pos, quat, names, seq_offsets, heights, frametimes, files):
+        self.pos, self.quat, self.body_names = pos, quat, names
+        self.seq_offsets, self.human_heights, self.frametimes, self.files = seq_offsets, heights, frametimes, files
+
+    def __len__(self):
+        return len(self.files)
+
+
+def load_lafan1_files(bvh_files, device: int = 0, threads: int = 8) -> BvhBatch:
+    """A folder's worth of BVH files -> one GPU batch (the file loop of scripts/bvh_to_robot_dataset.py:59-80, where every file
+    is parsed with regexes and turned into per-frame dicts one after the other).  The text of the files is parsed on ``threads``
+    host threads (both native parsers release the GIL), the clips are concatenated, and ONE ``gmr_bvh_fk`` launch does Euler ->
+    quaternion, the skeleton FK, Y-up -> Z-up, cm -> m and the FootMod synthesis for all of them.  All files must share one
+    skeleton (names, parents, Euler order), as a dataset does; the height estimate of every clip (lafan1.py:45-69, from its own
+    last frame) comes back with the batch."""
+    from concurrent.futures import ThreadPoolExecutor
+    files = [str(f) for f in bvh_files]
+    if not files:
+        raise ValueError("no files")
+    with ThreadPoolExecutor(max_workers=max(1, min(threads, len(files)))) as ex:
+        anims = list(ex.map(read_bvh, files))
+    a0 = anims[0]
+    for f, a in zip(files, anims):
+        if a.bones != a0.bones or not np.array_equal(a.parents, a0.parents) or a.order != a0.order:
+            raise ValueError(f"{f}: skeleton differs from {files[0]} (one batch = one skeleton)")
+    lib = _native.load()
+    dev = torch.device("cuda", device)
+    lens = np.array([a.pos.shape[0] for a in anims], dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    N, J = int(offs[-1]), len(a0.bones)
+    extra_names, extra_pos, extra_rot = [], [], []
+    for side in ("Left", "Right"):
+        if f"{side}Foot" in a0.bones and f"{side}Toe" in a0.bones:  # lafan1.py:36-39
+            extra_names.append(f"{side}FootMod")
+            extra_pos.append(a0.bones.index(f"{side}Foot"))
+            extra_rot.append(a0.bones.index(f"{side}Toe"))
+    E = len(extra_names)
+    lp_h = torch.empty((N, J, 3), dtype=torch.float64, pin_memory=True)
+    er_h = torch.empty((N, J, 3), dtype=torch.float64, pin_memory=True)
+    for a, o in zip(anims, offs[:-1]):
+        n = a.pos.shape[0]
+        lp_h[o:o + n] = torch.from_numpy(a.pos)
+        np.radians(a.eulers_deg, out=er_h[o:o + n].numpy())
+    lp, er = lp_h.to(dev, non_blocking=True), er_h.to(dev, non_blocking=True)
+    pos = torch.empty((N, J + E, 3), dtype=torch.float64, device=dev)
+    quat = torch.empty((N, J + E, 4), dtype=torch.float64, device=dev)
+    names = list(a0.bones) + extra_names
+    if N > 0:
+        parents = np.ascontiguousarray(a0.parents, dtype=np.int32)
+        order = np.asarray(a0.order, dtype=np.int32)
+        ep, erot = np.asarray(extra_pos, dtype=np.int32), np.asarray(extra_rot, dtype=np.int32)
+        vp = C.c_void_p
+        rc = lib.gmr_bvh_fk(parents.ctypes.data_as(vp), J, order.ctypes.data_as(vp), ep.ctypes.data_as(vp) if E else None,
+                            erot.ctypes.data_as(vp) if E else None, E, vp(lp.data_ptr()), vp(er.data_ptr()), N, 0.01,
+                            vp(pos.data_ptr()), vp(quat.data_ptr()), vp(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"gmr_bvh_fk failed with status {rc} ({J} joints, {E} extra)")
+    heights = []
+    if N > 0:
+        last = pos[torch.from_numpy(offs[1:][lens > 0] - 1).to(dev)].cpu().numpy()  # every clip's last frame
+        k = 0
+        for n in lens:
+            if n == 0:
+                heights.append(1.75)
+                continue
+            heights.append(_estimate_height({nm: last[k, i] for i, nm in enumerate(names)}))
+            k += 1
+    else:
+        heights = [1.75] * len(files)
+    return BvhBatch(pos, quat, names, offs, heights, [a.frametime for a in anims], files)

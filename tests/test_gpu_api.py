@@ -689,3 +689,35 @@ def test_c_abi_from_plain_c(tmp_path):
     ident[:, 3] = 1.0
     bp_ref, _ = orc.fk_kin(np.zeros((N, 3), np.float32), ident, q[:, 7:].astype(np.float32), want_rot=False)
     assert np.abs(bp - bp_ref).max() < 2e-6
+
+
+def test_bvh_folder_to_robot_batch(golden_dir, tmp_path):
+    """scripts/bvh_to_robot_dataset.py's file loop as one batch: load_lafan1_files (threaded native parse, one gmr_bvh_fk launch)
+    -> retarget_batch with every clip's own height -> the same qpos as loading and retargeting the files one by one; poses equal
+    the reference loader's goldens."""
+    import shutil
+    from gmr_amd import GeneralMotionRetargeting as GMR
+    from gmr_amd.bvh import load_lafan1_file, load_lafan1_files
+    src = os.path.join(golden_dir, "bvh_lafan_like.bvh")
+    text = open(src).read().split("\n")
+    k = next(i for i, ln in enumerate(text) if ln.startswith("Frame Time"))
+    rows = [ln for ln in text[k + 1:] if ln.strip()]
+    files = []
+    for j, n in enumerate((len(rows), 11, 23)):                       # the golden clip and two shorter cuts of it
+        p = tmp_path / f"clip{j}.bvh"
+        p.write_text("\n".join(text[:k - 1] + [f"Frames: {n}", text[k]] + rows[:n]) + "\n")
+        files.append(str(p))
+    batch = load_lafan1_files(files, threads=3)
+    gold = np.load(os.path.join(golden_dir, "bvh_lafan_like.npz"))
+    assert batch.body_names == [str(n) for n in gold["names"]] and list(batch.seq_offsets) == [0, len(rows), len(rows) + 11, len(rows) + 34]
+    assert np.abs(batch.pos[: len(rows)].cpu().numpy() - gold["pos"]).max() < 1e-9
+    g = GMR(src_human="bvh", tgt_robot="unitree_g1")
+    q = g.retarget_batch(batch.pos, batch.quat, batch.body_names, seq_offsets=batch.seq_offsets, human_heights=batch.human_heights)
+    for j, f in enumerate(files):
+        clip = load_lafan1_file(f)
+        assert abs(clip.human_height - batch.human_heights[j]) < 1e-12
+        q1 = GMR(src_human="bvh", tgt_robot="unitree_g1", actual_human_height=clip.human_height).retarget_batch(clip.pos, clip.quat, clip.body_names)
+        a, b = int(batch.seq_offsets[j]), int(batch.seq_offsets[j + 1])
+        assert float((q[a:b] - q1).abs().max().item()) < 1e-9
+    with pytest.raises(ValueError):
+        load_lafan1_files([files[0], os.path.join(golden_dir, "bvh_canonical_40f.bvh")])   # another skeleton
