@@ -36,7 +36,7 @@ def write_files(tmpd, n_files, T, seed=0):
         hdr.append(f"{ind}\tOFFSET {o[0]:.6f} {o[1]:.6f} {o[2]:.6f}")
         hdr.append(f"{ind}\tCHANNELS 6 Xposition Yposition Zposition Zrotation Yrotation Xrotation" if parent < 0 else f"{ind}\tCHANNELS 3 Zrotation Yrotation Xrotation")
         if not children[i]:
-            hdr += [f"{ind}\tEnd Site", ind + "\t{", f"{ind}\t\tOFFSET 0.000000 5.000000 0.000000", ind + "\t}"]
+            hdr.extend([f"{ind}\tEnd Site", ind + "\t{", f"{ind}\t\tOFFSET 0.000000 5.000000 0.000000", ind + "\t}"])
         for c in children[i]:
             emit(c, depth + 1)
         hdr.append(ind + "}")
