@@ -49,6 +49,22 @@ def test_fk_golden(robot, golden_dir, dev):
     assert np.abs(bp0.cpu().numpy() - g["local_body_pos"]).max() < 2e-6
 
 
+@pytest.mark.parametrize("robot", ["unitree_g1", "unitree_g1_with_hands", "booster_t1"])
+def test_fk_golden_wide_inputs(robot, golden_dir, dev):
+    """Both FK kernels (fk_pos_kernel for positions only, fk_kernel<0> with rotations) against the reference-generated vectors with
+    angles of +-7 rad, exact 0 / +-pi / 2 pi, +-50 m root positions and non-unit root quaternions (make_golden_wide.py)."""
+    cm = compiled("smplx", robot)
+    eng = _engine(cm)
+    g = np.load(os.path.join(golden_dir, f"fk_{robot}_wide.npz"))
+    rp, rr, dp = (torch.from_numpy(g[k]).to(dev) for k in ("root_pos", "root_rot", "dof_pos"))
+    tol_p, tol_r = 2e-6 * max(1.0, np.abs(g["body_pos"]).max()), 2e-6 * max(1.0, np.abs(g["body_rot"]).max())
+    bp, br = eng.fk(rp, rr, dp)
+    assert np.abs(bp.cpu().numpy() - g["body_pos"]).max() < tol_p and np.abs(br.cpu().numpy() - g["body_rot"]).max() < tol_r
+    bp2, _ = eng.fk(rp, rr, dp, want_rot=False)
+    assert np.abs(bp2.cpu().numpy() - g["body_pos"]).max() < tol_p
+    assert torch.equal(bp, bp2)  # the two kernels run the same chain
+
+
 @pytest.mark.parametrize("robot", CONFIG_ROBOTS)
 @pytest.mark.parametrize("hard", [False, True])
 @pytest.mark.parametrize("qp", ["structured", "generic"])

@@ -51,6 +51,18 @@ def test_fk_kin_matches_reference_golden(robot, golden_dir):
     assert np.abs(bp0 - g["local_body_pos"]).max() < 2e-6
 
 
+@pytest.mark.parametrize("robot", ["unitree_g1", "unitree_g1_with_hands", "booster_t1"])
+def test_fk_kin_matches_reference_golden_wide_inputs(robot, golden_dir):
+    """The same against the second reference-generated set (tests/golden/make_golden_wide.py): angles of +-7 rad, exact 0 / +-pi /
+    2 pi, root positions of +-50 m, root quaternions that are not unit (the reference multiplies them as they come).  Tolerance
+    2e-6 relative to the largest magnitude in play (positions up to 55 m, quaternion entries up to 4)."""
+    cm = compiled("smplx", robot)
+    g = np.load(os.path.join(golden_dir, f"fk_{robot}_wide.npz"))
+    bp, br = Oracle(cm.blob).fk_kin(g["root_pos"], g["root_rot"], g["dof_pos"])
+    assert np.abs(bp - g["body_pos"]).max() < 2e-6 * max(1.0, np.abs(g["body_pos"]).max())
+    assert np.abs(br - g["body_rot"]).max() < 2e-6 * max(1.0, np.abs(g["body_rot"]).max())
+
+
 def test_quat_mul_convention(golden_dir):
     """wxyz Hamilton product agrees with reference rot_utils.quat_mul_np (golden)."""
     g = np.load(os.path.join(golden_dir, "quat_mul_wxyz.npz"))
