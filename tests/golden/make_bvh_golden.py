@@ -79,15 +79,21 @@ def dump(bvh, npz):
     print(os.path.basename(bvh), pos.shape, h)
 
 
-def main():
-    src = os.path.join(REF, "out", "test_canonical.bvh")
-    lines = open(src).read().split("\n")
+def cut(src_name, dst_stem, first, count):
+    """Motion rows [first, first + count) of one of the reference's clips as a small fixture + the reference loader's output."""
+    lines = open(os.path.join(REF, "out", src_name)).read().split("\n")
     k = next(i for i, ln in enumerate(lines) if ln.startswith("Frames:"))
-    head, rows = lines[:k], [ln for ln in lines[k + 2:] if ln.strip()][:40]
-    small = os.path.join(HERE, "bvh_canonical_40f.bvh")
+    head, rows = lines[:k], [ln for ln in lines[k + 2:] if ln.strip()][first:first + count]
+    small = os.path.join(HERE, dst_stem + ".bvh")
     with open(small, "w") as f:
-        f.write("\n".join(head + ["Frames: 40", lines[k + 1]] + rows) + "\n")
-    dump(small, os.path.join(HERE, "bvh_canonical_40f.npz"))
+        f.write("\n".join(head + [f"Frames: {len(rows)}", lines[k + 1]] + rows) + "\n")
+    dump(small, os.path.join(HERE, dst_stem + ".npz"))
+
+
+def main():
+    cut("test_canonical.bvh", "bvh_canonical_40f", 0, 40)
+    # the 87-joint pruned clip (another hierarchy: fewer finger / twist bones), frames from the middle of the motion
+    cut("test_canonical_pruned.bvh", "bvh_pruned_mid_24f", 120, 24)
     syn = os.path.join(HERE, "bvh_lafan_like.bvh")
     write_lafan_like(syn)
     dump(syn, os.path.join(HERE, "bvh_lafan_like.npz"))

@@ -175,7 +175,7 @@ def test_model_create_fails_loudly_without_a_device():
 
 def test_bvh_parser_follows_reference_file_semantics(golden_dir, tmp_path):
     from gmr_amd.bvh import read_bvh
-    for name, nj in (("bvh_canonical_40f", 101), ("bvh_lafan_like", 22)):
+    for name, nj in (("bvh_canonical_40f", 101), ("bvh_lafan_like", 22), ("bvh_pruned_mid_24f", 87)):
         a = read_bvh(os.path.join(golden_dir, name + ".bvh"))
         g = np.load(os.path.join(golden_dir, name + ".npz"))
         assert a.bones == [str(n) for n in g["names"]][:nj] and a.order == (2, 1, 0)  # "Zrotation Yrotation Xrotation"
