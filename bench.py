@@ -61,6 +61,10 @@ def parse_args(argv=None):
     ap.add_argument("--hot-only", action="store_true", help="only the warmup + timed launches of the headline workload (no other legs): the "
                     "form profiled under rocprofv3 so the kernel's average duration is that of the timed launch")
     ap.add_argument("--hot-fk", action="store_true", help="with --hot-only: also run the timed fk_kernel launches (profiles/r02_fk_*)")
+    ap.add_argument("--traffic", choices=["auto", "pmc", "const"], default="auto",
+                    help="roofline.traffic: 'pmc' measures HBM bytes of ik_kernel in this run (two child rocprofv3 --pmc passes over a short "
+                         "--hot-only launch, FETCH_SIZE x 2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes); 'const' uses the figure of the "
+                         "committed profile; 'auto' = pmc when rocprofv3 is available and this is a plain 1-GPU run, else const")
     return ap.parse_args(argv)
 
 
@@ -88,6 +92,41 @@ def self_launch(args) -> int:
     if line is not None:
         print(line, flush=True)
     return rc if rc != 0 else (0 if line is not None else 1)
+
+
+def measure_traffic_pmc(frames=600, clips=8192, timeout=240):
+    """HBM bytes per frame of ik_kernel from PMC counters, measured now: one child `rocprofv3 --pmc C --kernel-trace` run per counter
+    (they do not fit one pass) over `bench.py --hot-only` with short clips.  Returns (bytes_per_frame, detail) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3")
+    if prof is None:
+        return None, "rocprofv3 not found"
+    if any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "already under a profiler"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="gmr_pmc_")
+        try:
+            cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--hot-only", "--steps", "1", "--warmup", "1", "--frames", str(frames), "--clips", str(clips), "--traffic", "const"]
+            r = subprocess.run(cmd, cwd=tempfile.gettempdir(), env=dict(os.environ, TMPDIR=tempfile.gettempdir()), capture_output=True, text=True, timeout=timeout)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"{counter} pass failed (rc {r.returncode})"
+            got = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0])) if "ik_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter]
+            if not got:
+                return None, f"no ik_kernel rows in the {counter} pass"
+            vals[counter] = got[-1]  # the timed launch (the last dispatch); KB
+        except Exception as ex:  # timeout, parse error: fall back to the committed figure
+            return None, f"{counter} pass: {ex!r}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    n = frames * clips
+    bpf = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0 / n  # gfx950 tallies 128-byte read requests at 64 bytes
+    return bpf, {"FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"], "frames_in_pass": n}
 
 
 def flops_per_solve(cm) -> float:
@@ -132,6 +171,11 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
+    # HBM traffic of the dominant kernel, measured in this run by child profiler passes -- taken first, before this process
+    # imports torch or touches the GPU
+    live_traffic = (None, "not requested")
+    if args.traffic == "pmc" or (args.traffic == "auto" and args.gpus == 1 and "WORLD_SIZE" not in os.environ and not args.hot_only):
+        live_traffic = measure_traffic_pmc()
 
     import numpy as np
     import torch
@@ -255,6 +299,14 @@ def main():
         ach_tf = fps_kernel * mean_solves * fsolve / 1e12
         measured = (MEASURED_TRAFFIC["robot"], MEASURED_TRAFFIC["src"], MEASURED_TRAFFIC["in_itemsize"]) == (ROBOT, SRC, in_sz)
         traffic = (MEASURED_TRAFFIC["bytes_per_frame"] if measured else bpf) * n_frames
+        traffic_source = (MEASURED_TRAFFIC["source"] + " (PMC, this configuration) scaled to this launch") if measured else "algorithmic bytes (no PMC pass for this configuration)"
+        if live_traffic[1] != "not requested":
+            live, detail = live_traffic
+            if live is not None:
+                traffic, traffic_source = live * n_frames, {"measured": "this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes over an 8192 x 600 launch, "
+                                                                        "(2 x FETCH + WRITE) per frame scaled to this launch", "bytes_per_frame": live, **detail}
+            else:
+                traffic_source += f"; live PMC pass not taken: {detail}"
         result = {
             "metric": "retargeted frames/sec (whole node), Unitree G1 29-DoF SMPLX; max qpos err vs CPU",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -269,8 +321,7 @@ def main():
                 "distinct_clips": D, "initial_heading_rad": 1.0,
             },
             "roofline": {"bound": "fp64-vector", "achieved": ach_tf, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s", "frac": ach_tf / FP64_VECTOR_PEAK_TF,
-                         "traffic": traffic, "traffic_source": (MEASURED_TRAFFIC["source"] + " (PMC, this configuration) scaled to this launch")
-                         if measured else "algorithmic bytes (no PMC pass for this configuration)",
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel_name, "kernel_ms": kern_ms, "flop_per_solve": fsolve, "mean_solves_per_frame": mean_solves,
                          "solves_per_frame_histogram": solves_hist,
                          "note": "achieved = SURVEY 8(d) flop/solve x measured solves/frame x frames / kernel time (HIP events)"},
