@@ -466,6 +466,13 @@ def main():
                                            "verified_chunked_frames_per_s": nfr / t_chk, "resolved_frames": info["resolved_frames"],
                                            "max_abs_diff_vs_sequential": float((q_chk - q_seq).abs().max().item()),
                                            "frames_with_different_solve_count": int((it_chk != it_seq).sum().item())}
+            if label == "any_heading":  # the opt-in departure from the reference: clips start on their root target (retarget_batch(clip_start=...))
+                from gmr_amd._native import INIT_ROOT_TARGET
+                t_rt, (q_rt, _, info_rt) = timed(lambda: lc["eng"].ik_solve_chunked(lc["pos"], lc["quat"], lc["sc"], lc["offs"], chunk=64, burn_in=32,
+                                                                                     clip_init=INIT_ROOT_TARGET), reps=3)
+                result["long_clips"]["any_heading_root_target_start"] = {
+                    "verified_chunked_frames_per_s": nfr / t_rt, "resolved_frames": info_rt["resolved_frames"],
+                    "note": "NOT the reference's semantics: every clip starts with the base on its first root target instead of qpos0"}
             del lc
         # BASELINE config 4: five robots' batches (5 x 64 clips x 1000 frames) as ONE launch (gmr_group_*) and as five launches on
         # five streams (round 1's form)

@@ -223,7 +223,7 @@ class Engine:
 
     def ik_solve_chunked(self, pos: torch.Tensor, quat: torch.Tensor, slot_col: np.ndarray, seq_offsets, chunk: int, burn_in: int,
                          params: Optional[IKParams] = None, eps: float = 1e-7, height_scales=None,
-                         chunk_init: int = _native.INIT_ROOT_TARGET):
+                         chunk_init: int = _native.INIT_ROOT_TARGET, clip_init: int = _native.INIT_QPOS0):
         """Parallel-in-time solve of long clips with *verified* chunk boundaries, in two launches.
 
         Launch 1 solves every chunk of ``chunk`` frames concurrently, each (but a clip's first) warmed up over
@@ -238,7 +238,7 @@ class Engine:
         """
         from .schedule import make_items, plan_walks
         offs = np.asarray(seq_offsets, dtype=np.int64)
-        items = make_items(offs, chunk=chunk, burn_in=burn_in, track=True, height_scales=height_scales, chunk_init=chunk_init)
+        items = make_items(offs, chunk=chunk, burn_in=burn_in, track=True, height_scales=height_scales, chunk_init=chunk_init, clip_init=clip_init)
         n = len(items)
         prm = params or IKParams()
         prm = IKParams(prm.damping, prm.tol, prm.limit_gain, prm.lm_damping, prm.max_iter, prm.offset_to_ground, eps)

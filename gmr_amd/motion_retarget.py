@@ -251,7 +251,7 @@ class GeneralMotionRetargeting:
     # ------------------------------------------------------------------ batched API
     def retarget_batch(self, pos, quat, body_names: Sequence[str], seq_offsets=None, chunk: int = 0, burn_in: int = 0,
                        offset_to_ground: bool = False, return_iters: bool = False, verify: bool = True,
-                       human_heights: Optional[Sequence[float]] = None, check: bool = True):
+                       human_heights: Optional[Sequence[float]] = None, check: bool = True, clip_start: str = "qpos0"):
         """Retarget whole clips in one launch.
 
         pos ``[N, B, 3]`` (m), quat ``[N, B, 4]`` (wxyz), float32/float64, numpy or CUDA torch; ``body_names`` names the
@@ -264,11 +264,18 @@ class GeneralMotionRetargeting:
         ``GeneralMotionRetargeting(src, robot, human_heights[s])`` whatever height this object was built with.  With ``check``
         (default) the result is inspected on the device -- non-finite qpos raises ``FloatingPointError`` (as ``retarget`` does),
         a QP that hit its iteration cap raises ``RuntimeError`` (mink asserts on a failed QP); this synchronises the stream.
+        ``clip_start="root_target"`` is an opt-in departure from the reference: every clip starts with the floating base on its
+        first frame's root target instead of ``qpos0`` at the world origin, which avoids the reference's slow -- for clips facing
+        away from ``qpos0`` sometimes never-ending -- start-up; the default reproduces the reference.
         Returns qpos ``[N, nq]`` float64 (same container kind as the input) and, optionally, solves per frame.
         """
         is_np = isinstance(pos, np.ndarray)
+        if clip_start not in ("qpos0", "root_target"):
+            raise ValueError("clip_start must be 'qpos0' (the reference) or 'root_target'")
+        from ._native import INIT_QPOS0, INIT_ROOT_TARGET
+        clip_init = INIT_ROOT_TARGET if clip_start == "root_target" else INIT_QPOS0
         cols = self._columns(list(body_names))  # KeyError where the reference raises
-        if is_np and isinstance(quat, np.ndarray) and chunk == 0 and pos.ndim == 3 and pos.shape[0] >= self.HOST_PIPELINE_MIN_FRAMES:
+        if is_np and isinstance(quat, np.ndarray) and chunk == 0 and clip_init == INIT_QPOS0 and pos.ndim == 3 and pos.shape[0] >= self.HOST_PIPELINE_MIN_FRAMES:
             # big host batches: two streams, copies overlapped with the kernel, pinned result (Engine.ik_solve_host)
             N = int(pos.shape[0])
             offs = np.asarray([0, N] if seq_offsets is None else seq_offsets, dtype=np.int64)
@@ -304,9 +311,9 @@ class GeneralMotionRetargeting:
             hs = hh / self._cm.config.human_height_assumption / self._cm.ratio
         if chunk > 0 and verify:
             out, iters, self.last_chunk_info = self._engine.ik_solve_chunked(
-                tpos, tquat, cols, offs, chunk, burn_in, params=self._params(offset_to_ground), height_scales=hs)
+                tpos, tquat, cols, offs, chunk, burn_in, params=self._params(offset_to_ground), height_scales=hs, clip_init=clip_init)
         else:
-            items = make_items(offs, chunk=chunk, burn_in=burn_in, height_scales=hs)
+            items = make_items(offs, chunk=chunk, burn_in=burn_in, height_scales=hs, clip_init=clip_init)
             out, iters, _ = self._engine.ik_solve(tpos, tquat, cols, items, params=self._params(offset_to_ground))
         if check and N > 0:
             bad = torch.stack([(~torch.isfinite(out)).any(), (iters >> 30).ne(0).any()]).cpu().numpy()

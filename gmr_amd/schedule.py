@@ -27,10 +27,13 @@ from ._native import INIT_QPOS0, INIT_ROOT_TARGET, WORK_ITEM_DTYPE
 
 
 def make_items(seq_offsets: Sequence[int], chunk: int = 0, burn_in: int = 0, track: bool = False,
-               height_scales: Optional[Sequence[float]] = None, chunk_init: int = INIT_ROOT_TARGET) -> np.ndarray:
+               height_scales: Optional[Sequence[float]] = None, chunk_init: int = INIT_ROOT_TARGET, clip_init: int = INIT_QPOS0) -> np.ndarray:
     """Work items of a batch of clips.  ``height_scales[s]`` is clip s's factor on the human scale table (its own
     ``actual_human_height`` over the height the model was compiled with, motion_retarget.py:36-43); ``chunk_init`` is the
-    start state of every chunk but a clip's first (which always starts from ``qpos0``, like the reference)."""
+    start state of every chunk but a clip's first.  ``clip_init`` is the start state of the clip itself: ``INIT_QPOS0`` is the
+    reference (a fresh ``GeneralMotionRetargeting`` per file); ``INIT_ROOT_TARGET`` is an opt-in departure from it -- the robot is
+    put where the human is before the first frame, which spares a clip that starts facing away from ``qpos0`` the reference's slow,
+    sometimes never-ending, start-up."""
     offs = np.asarray(seq_offsets, dtype=np.int64)
     if offs.ndim != 1 or offs.size < 1 or np.any(np.diff(offs) < 0):
         raise ValueError("seq_offsets must be a non-decreasing 1-D array")
@@ -43,12 +46,12 @@ def make_items(seq_offsets: Sequence[int], chunk: int = 0, burn_in: int = 0, tra
         if b == a:
             continue
         if chunk <= 0:
-            rows.append((a, 0, b - a, INIT_QPOS0, -1, -1, 0, hs[s]))
+            rows.append((a, 0, b - a, clip_init, -1, -1, 0, hs[s]))
             continue
         for start in range(a, b, chunk):
             n_out = min(chunk, b - start)
             burn = min(burn_in, start - a)
-            rows.append((start - burn, burn, n_out, INIT_QPOS0 if start == a else chunk_init, -1, -1, 0, hs[s]))
+            rows.append((start - burn, burn, n_out, clip_init if start == a else chunk_init, -1, -1, 0, hs[s]))
     items = np.array(rows, dtype=WORK_ITEM_DTYPE) if rows else np.zeros(0, dtype=WORK_ITEM_DTYPE)
     if track:  # final state of item i -> row i, state after burn-in -> row n + i (see plan_walks)
         n = len(items)

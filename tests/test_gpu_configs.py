@@ -196,3 +196,26 @@ def test_long_clips_any_heading_chunked_equals_sequential():
     assert 0 <= info["resolved_frames"] <= sum(lens)
     q_ref, it_ref, _ = Oracle(cm.blob).ik_solve(pos[: lens[0]].cpu().numpy(), quat[: lens[0]].cpu().numpy(), sc, make_items([0, lens[0]], height_scales=hs[:1]))
     assert np.abs(q_chk[: lens[0]].cpu().numpy() - q_ref).max() < 1e-6 and np.array_equal((it_chk[: lens[0]] & 0x3FFFFFFF).cpu().numpy(), it_ref)
+
+
+def test_clip_start_on_root_target_is_opt_in():
+    """retarget_batch(clip_start="root_target"): clips start with the base on their first root target (NOT the reference's qpos0
+    start; opt-in).  Same as the oracle's INIT_ROOT_TARGET items; on clips that start facing away from qpos0 it spares the slow
+    start-up (fewer solves), and every speculative chunk verifies."""
+    from gmr_amd import GeneralMotionRetargeting as GMR
+    from gmr_amd._native import INIT_ROOT_TARGET
+    g = GMR("bvh", "unitree_g1")
+    cm = g._cm
+    lens = [400, 300, 500]
+    pos, quat, names, offs = synth.synth_clips_torch(cm, lens, seed=33, device=g.device, hard=False, yaw0=np.pi)
+    q_ref_start, it_ref_start = g.retarget_batch(pos, quat, names, seq_offsets=offs, return_iters=True)
+    q_rt, it_rt = g.retarget_batch(pos, quat, names, seq_offsets=offs, return_iters=True, clip_start="root_target")
+    sc = cm.slot_columns(names)
+    items = make_items(offs, clip_init=INIT_ROOT_TARGET)
+    q_o, it_o, _ = Oracle(cm.blob).ik_solve(pos.cpu().numpy(), quat.cpu().numpy(), sc, items)
+    assert np.abs(q_rt.cpu().numpy() - q_o).max() < 1e-6 and np.array_equal((it_rt & 0x3FFFFFFF).cpu().numpy(), it_o)
+    assert float((it_rt & 0x3FFFFFFF).float().mean()) <= float((it_ref_start & 0x3FFFFFFF).float().mean())
+    q_c = g.retarget_batch(pos, quat, names, seq_offsets=offs, chunk=32, burn_in=24, clip_start="root_target")
+    assert float((q_c - q_rt).abs().max().item()) < 1e-6 and g.last_chunk_info["resolved_frames"] <= 64
+    with pytest.raises(ValueError):
+        g.retarget_batch(pos, quat, names, clip_start="nowhere")
