@@ -83,7 +83,8 @@ def read_bvh(filename: str) -> BvhAnim:
     names, parents, offsets, chan, order, fnum, frametime, moff = _parse_header(raw, filename)
     motion_block = raw[moff:]
     channels = int(chan[-1])  # the reference shapes the motion rows by the LAST joint's channel count (extract.py:104-106)
-    if (channels == 3 and (chan[0] not in (3, 6) or np.any(chan[1:] != 3))) or (channels == 6 and np.any(chan != 6)):
+    if (channels == 3 and (chan[0] not in (3, 6) or np.any(chan[1:] != 3))) or (channels == 6 and np.any(chan != 6)) \
+            or (channels == 9 and (chan[0] != 3 or np.any(chan[1:] != 9))):
         raise NotImplementedError(f"{filename}: joints with mixed channel counts are not supported")
     J = len(names)
     data = _parse_motion(motion_block, fnum, 9 * J + 3, filename)  # the ctypes call releases the GIL: files parse in parallel threads
@@ -102,6 +103,16 @@ def read_bvh(filename: str) -> BvhAnim:
         blk = data.reshape(fnum, J, 6)
         positions = blk[:, :, 0:3].copy()
         rotations = blk[:, :, 3:6].copy()
+    elif channels == 9:
+        # extract.py:152-156: three root position values, then (position, rotation, scale) per non-root joint; a joint's local
+        # position is its offset plus position * scale, the root keeps a zero rotation
+        if len(names) < 2 or data.shape[1] != 3 + 9 * (J - 1):
+            raise ValueError(f"{filename}: expected {3 + 9 * (J - 1)} columns, found {data.shape[1]}")
+        positions[:, 0] = data[:, 0:3]
+        blk = data[:, 3:].reshape(fnum, J - 1, 9)
+        positions[:, 1:] += blk[:, :, 0:3] * blk[:, :, 6:9]
+        rotations = np.zeros((fnum, J, 3))
+        rotations[:, 1:] = blk[:, :, 3:6]
     else:
         raise NotImplementedError(f"{filename}: {channels}-channel joints are not supported")
     return BvhAnim(names, np.asarray(parents, dtype=np.int32), offs, order, positions, rotations, frametime)

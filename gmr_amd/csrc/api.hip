@@ -1295,6 +1295,7 @@ int gmr_bvh_parse_header(const char *text, size_t len, int max_joints, char *nam
   if (!c.next() || !c.is("HIERARCHY") || !c.next() || !c.is("ROOT")) return -1;
   int rc = gmr_bvh::joint(c, h, -1, 0);
   if (rc) return rc;
+  if (h.order[0] < 0) return -1;  // no joint names three rotation channels where the reference looks for the Euler order
   int64_t nf;
   double ft;
   if (!c.next() || !c.is("MOTION") || !c.next() || !c.is("Frames:") || !gmr_bvh::integer(c, nf) || !c.next() || !c.is("Frame") ||

@@ -6,11 +6,12 @@
 //   file     := "HIERARCHY" joint "MOTION" "Frames:" INT "Frame" "Time:" NUM  <motion rows>
 //   joint    := ("ROOT" | "JOINT") NAME "{" "OFFSET" NUM NUM NUM "CHANNELS" INT CHANNEL{INT} (joint | endsite)* "}"
 //   endsite  := "End" "Site" "{" "OFFSET" NUM NUM NUM "}"
-//   CHANNEL  := ("X" | "Y" | "Z") ("position" | "rotation")
+//   CHANNEL  := ("X" | "Y" | "Z") ("position" | "rotation" | "scale")
 //
 // Semantics kept from the reference so that files load identically: joints are numbered in the order they appear; an
-// end site contributes nothing; the Euler order is read off the LAST three channels of the FIRST joint (:107-113), which
-// must be rotations; the per-joint channel count that shapes the motion rows is the LAST joint's (:104-106), reported per
+// end site contributes nothing; the Euler order is read off the first joint whose channels 0-2 (a 3-channel joint) or 3-5
+// (any other count) are all rotations (:104-113: a positions-only root of the 9-channel layout is skipped and the next joint
+// decides); the per-joint channel count that shapes the motion rows is the LAST joint's (:104-106), reported per
 // joint here so the caller can reject mixed files it cannot lay out; NAME keeps the leading run of [A-Za-z0-9_] of its token
 // (the reference captures `\w+`); numbers are decimal literals rounded like Python's float() (strtod).
 #pragma once
@@ -94,19 +95,18 @@ inline int joint(Cursor &c, Header &h, int parent, int depth) {
       if (have_channels || !integer(c, k) || k < 0 || k > 9) return -1;
       int axes[9];
       for (int i = 0; i < (int)k; ++i) {
-        if (!c.next() || c.len != 9 || c.tok[0] < 'X' || c.tok[0] > 'Z') return -1;
-        const bool rot = memcmp(c.tok + 1, "rotation", 8) == 0, pos = memcmp(c.tok + 1, "position", 8) == 0;
-        if (!rot && !pos) return -1;
+        if (!c.next() || c.len < 6 || c.tok[0] < 'X' || c.tok[0] > 'Z') return -1;
+        const bool rot = c.len == 9 && memcmp(c.tok + 1, "rotation", 8) == 0, pos = c.len == 9 && memcmp(c.tok + 1, "position", 8) == 0;
+        const bool scl = c.len == 6 && memcmp(c.tok + 1, "scale", 5) == 0;
+        if (!rot && !pos && !scl) return -1;
         axes[i] = rot ? c.tok[0] - 'X' : -1;
       }
       h.channels[me] = (int32_t)k;
       have_channels = true;
-      if (me == 0) {  // Euler order: the last three channels of the first joint
-        if (k < 3) return -1;
-        for (int i = 0; i < 3; ++i) {
-          if (axes[k - 3 + i] < 0) return -1;
-          h.order[i] = axes[k - 3 + i];
-        }
+      if (h.order[0] < 0) {  // Euler order: first joint whose rotation slice (0-2 of a 3-channel joint, else 3-5) is all rotations
+        const int lo = k == 3 ? 0 : 3;
+        if (lo + 3 <= (int)k && axes[lo] >= 0 && axes[lo + 1] >= 0 && axes[lo + 2] >= 0)
+          for (int i = 0; i < 3; ++i) h.order[i] = axes[lo + i];
       }
     } else if (c.is("JOINT")) {
       int rc = joint(c, h, me, depth + 1);

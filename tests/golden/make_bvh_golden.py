@@ -8,6 +8,8 @@ Inputs written next to this script (data, not code):
   Character-Creator skeleton; no LAFAN foot names, so no FootMod entries and the 1.75 m height fallback)
 * ``bvh_lafan_like.bvh``     -- a synthetic 22-joint skeleton with LAFAN1 bone names (exercises LeftFootMod /
   RightFootMod and the Head-minus-foot height estimate)
+* ``bvh_nine_channel.bvh``   -- the same skeleton in the legacy 9-channel layout (positions-only root; position, rotation
+  and scale per joint), the third row shape the reference's reader accepts
 Outputs: ``bvh_*.npz`` with ``names``, ``pos [T,B,3]``, ``quat [T,B,4]`` (wxyz), ``human_height`` as returned by
 ``general_motion_retargeting.utils.lafan1.load_lafan1_file``.
 """
@@ -70,6 +72,40 @@ def write_lafan_like(path, T=30, seed=0):
         f.write("\n".join(out) + "\n")
 
 
+def write_nine_channel(path, T=12, seed=3):
+    """The legacy layout of extract.py:152-156: a positions-only root, (position, rotation, scale) per other joint."""
+    rng = np.random.default_rng(seed)
+    children = {i: [j for j, (_, p) in enumerate(LAFAN) if p == i] for i in range(len(LAFAN))}
+    out = ["HIERARCHY"]
+
+    def emit(i, depth):
+        name, parent = LAFAN[i]
+        ind = "  " * depth
+        out.append(f"{ind}{'ROOT' if parent < 0 else 'JOINT'} {name}")
+        out.append(ind + "{")
+        o = OFFS[name]
+        out.append(f"{ind}  OFFSET {o[0]:.6f} {o[1]:.6f} {o[2]:.6f}")
+        if parent < 0:
+            out.append(f"{ind}  CHANNELS 3 Xposition Yposition Zposition")
+        else:
+            out.append(f"{ind}  CHANNELS 9 Xposition Yposition Zposition Zrotation Yrotation Xrotation Xscale Yscale Zscale")
+        if not children[i]:
+            out.extend([f"{ind}  End Site", ind + "  {", f"{ind}    OFFSET 0.000000 5.000000 0.000000", ind + "  }"])
+        for c in children[i]:
+            emit(c, depth + 1)
+        out.append(ind + "}")
+
+    emit(0, 0)
+    out += ["MOTION", f"Frames: {T}", "Frame Time: 0.0333333"]
+    for t in range(T):
+        row = [2.0 * t, 92.0 + np.cos(t / 4.0), -1.0 * t]
+        for _ in range(len(LAFAN) - 1):
+            row += rng.normal(0, 0.5, 3).tolist() + rng.normal(0, 8.0, 3).tolist() + rng.uniform(0.9, 1.1, 3).tolist()
+        out.append(" ".join(f"{v:.6f}" for v in row))
+    with open(path, "w") as f:
+        f.write("\n".join(out) + "\n")
+
+
 def dump(bvh, npz):
     frames, h = load_lafan1_file(bvh)
     names = list(frames[0].keys())
@@ -97,6 +133,9 @@ def main():
     syn = os.path.join(HERE, "bvh_lafan_like.bvh")
     write_lafan_like(syn)
     dump(syn, os.path.join(HERE, "bvh_lafan_like.npz"))
+    nine = os.path.join(HERE, "bvh_nine_channel.bvh")
+    write_nine_channel(nine)
+    dump(nine, os.path.join(HERE, "bvh_nine_channel.npz"))
 
 
 if __name__ == "__main__":

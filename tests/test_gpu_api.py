@@ -243,7 +243,7 @@ def test_dataset_path_matches_reference_postprocessing(tmp_path):
     assert np.abs(bvh[0]["root_pos"] - q_ref[:50, :3]).max() < 1e-6
 
 
-@pytest.mark.parametrize("name", ["bvh_canonical_40f", "bvh_lafan_like", "bvh_pruned_mid_24f"])
+@pytest.mark.parametrize("name", ["bvh_canonical_40f", "bvh_lafan_like", "bvh_pruned_mid_24f", "bvh_nine_channel"])
 def test_bvh_adapter_matches_reference_loader(name, golden_dir):
     """gmr_amd.bvh.load_lafan1_file (host parse + gmr_bvh_fk) vs the reference's load_lafan1_file output (golden)."""
     from gmr_amd.bvh import load_lafan1_file

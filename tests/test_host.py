@@ -183,6 +183,13 @@ def test_bvh_parser_follows_reference_file_semantics(golden_dir, tmp_path):
         np.testing.assert_array_equal(a.pos[:, 1:], np.repeat(a.offsets[None, 1:], a.pos.shape[0], axis=0))  # non-root = joint offsets
         # root translation (cm, Y-up) -> golden root position (m, Z-up): (x, y, z) -> (x, -z, y) / 100
         np.testing.assert_allclose(np.stack([a.pos[:, 0, 0], -a.pos[:, 0, 2], a.pos[:, 0, 1]], -1) / 100, g["pos"][:, 0], atol=1e-12)
+    # the legacy 9-channel layout (extract.py:152-156): positions-only root, (position, rotation, scale) per joint; the Euler
+    # order comes from the first joint that has rotations, the root keeps a zero rotation
+    a = read_bvh(os.path.join(golden_dir, "bvh_nine_channel.bvh"))
+    g = np.load(os.path.join(golden_dir, "bvh_nine_channel.npz"))
+    assert a.bones == [str(n) for n in g["names"]][:22] and a.order == (2, 1, 0) and a.pos.shape == a.eulers_deg.shape == (12, 22, 3)
+    assert not a.eulers_deg[:, 0].any() and a.eulers_deg[:, 1:].any() and np.abs(a.pos[:, 1:] - a.offsets[None, 1:]).max() > 0.1
+    np.testing.assert_allclose(np.stack([a.pos[:, 0, 0], -a.pos[:, 0, 2], a.pos[:, 0, 1]], -1) / 100, g["pos"][:, 0], atol=1e-12)
     bad = tmp_path / "bad.bvh"
     bad.write_text("HIERARCHY\nROOT a\n{\nOFFSET 0 0 0\nCHANNELS 6 Xposition Yposition Zposition Zrotation Yrotation Xrotation\n}\nMOTION\nFrames: 2\nFrame Time: 0.03\n0 0 0 0 0 0\n")
     with pytest.raises(ValueError):
@@ -220,7 +227,7 @@ def test_bvh_motion_parser_matches_python_float():
 
 def test_bvh_header_tokenizer_grammar(tmp_path):
     """gmr_bvh_parse_header (gmr_amd/csrc/bvh_text.h): the token grammar accepts any line structure, keeps the reference's file
-    semantics (joint order, End Sites ignored, Euler order from the first joint's last three channels, `\\w+` names) and rejects
+    semantics (joint order, End Sites ignored, Euler order from the first joint with a rotation triple, `\\w+` names) and rejects
     what it cannot lay out -- including truncated and garbage input."""
     from gmr_amd.bvh import read_bvh, _parse_header
     one_line = ("HIERARCHY ROOT Hips { OFFSET 0 1.5 -2e-1 CHANNELS 6 Xposition Yposition Zposition Zrotation Yrotation Xrotation "
@@ -256,7 +263,7 @@ def test_bvh_header_tokenizer_grammar(tmp_path):
             read_bvh(str(p))
     nine = one_line.replace("CHANNELS 3 Zrotation Yrotation Xrotation JOINT Foot", "CHANNELS 9 Xposition Yposition Zposition Zrotation Yrotation Xrotation Xposition Yposition Zposition JOINT Foot")
     p.write_text(nine)
-    with pytest.raises(NotImplementedError):                                                         # mixed / 9-channel joints: rejected, not mis-read
+    with pytest.raises(NotImplementedError):                                                         # mixed channel counts: rejected, not mis-read
         read_bvh(str(p))
     # many joints: the name / joint capacity grows
     deep = "HIERARCHY ROOT j0 { OFFSET 0 0 0 CHANNELS 6 Xposition Yposition Zposition Zrotation Yrotation Xrotation " + \
