@@ -232,7 +232,18 @@ int build_device_model(gmr_model *m) {
   // ---- active dofs: root 6 + hinges with at least one task (either table) at or below them ----
   std::vector<int> abody, akind, aqadr, alim;
   std::vector<double> arange;
-  for (int k = 0; k < 6; ++k) { abody.push_back(0); akind.push_back(k); aqadr.push_back(k < 3 ? k : 3); alim.push_back(0); arange.push_back(0); arange.push_back(0); }
+  // the root's six rows.  A planar base (gmr_blob.h root_dof_mask 0x23) keeps all six in the QP, with z / roll / pitch as *null*
+  // dofs (kind 7): the kernel's hinge path gives them the root body's hinge axis -- zero -- hence a zero screw, a zero gradient,
+  // a diagonal of damping alone and dq = 0 exactly: the reference's 27-dof problem solved inside the 30-row one, with no
+  // branch added to the kernel (rows 3, 4, 5 stay the root's rotation step: 0, 0, yaw).  They keep their place in the
+  // elimination order but are left out of the ancestor relation (no H pairs) and of the structured QP's core.
+  const int root_mask = h.root_dof_mask ? h.root_dof_mask : 0x3F;
+  if (root_mask != 0x3F && root_mask != 0x23) { set_err(m, "root_dof_mask 0x%x: only a free joint (0x3f) or a planar base (0x23) is supported", root_mask); return GMR_EUNSUPPORTED; }
+  if (axis[0] != 0.0 || axis[1] != 0.0 || axis[2] != 0.0) { set_err(m, "the root body must not carry a hinge axis"); return GMR_EINVAL; }
+  for (int k = 0; k < 6; ++k) {
+    abody.push_back(0); akind.push_back(((root_mask >> k) & 1) ? k : 7); aqadr.push_back(k < 3 ? k : 3); alim.push_back(0); arange.push_back(0); arange.push_back(0);
+  }
+  const int n_root = 6;
   for (int b = 1; b < nb; ++b) {
     if (jtype[b] != GMR_JNT_HINGE) continue;
     bool used = false;
@@ -248,8 +259,8 @@ int build_device_model(gmr_model *m) {
   // ancestor relation among active dofs in depth-first order (j above i implies j < i)
   auto dfs_anc = [&](int j, int i) {
     if (j >= i) return false;
-    if (akind[i] < 6) return true;       // root dofs form a chain 0 <- 1 <- ... <- 5
-    if (akind[j] < 6) return true;       // every hinge hangs below the root's six dofs
+    if (akind[i] != 6) return true;      // root dofs (null ones included) form a chain 0 <- 1 <- ... <- 5
+    if (akind[j] != 6) return true;      // every hinge hangs below the root's six dofs
     return abody[j] != abody[i] && above(abody[j], abody[i]);
   };
   // ---- elimination order of the QP: sort dofs by height (longest chain of dofs below), tallest first.  Dofs of equal
@@ -262,10 +273,10 @@ int build_device_model(gmr_model *m) {
   std::vector<u64> anc_dfs(n_act, 0);  // relation in depth-first indices, taken before the arrays are permuted
   for (int i = 0; i < n_act; ++i)
     for (int j = 0; j < i; ++j)
-      if (dfs_anc(j, i)) anc_dfs[i] |= 1ull << j;
+      if (dfs_anc(j, i) && akind[i] != 7 && akind[j] != 7) anc_dfs[i] |= 1ull << j;  // a null dof keeps its place in the order but couples with nothing
   std::iota(perm.begin(), perm.end(), 0);
   std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return height[a] > height[b]; });
-  for (int k = 0; k < 6; ++k)
+  for (int k = 0; k < n_root; ++k)
     if (perm[k] != k) { set_err(m, "internal: root dofs must lead the elimination order"); return GMR_EINVAL; }
   {
     std::vector<int> b2(n_act), k2(n_act), q2(n_act), l2(n_act), h2(n_act);
@@ -332,7 +343,7 @@ int build_device_model(gmr_model *m) {
       for (int j = 0; j < i; ++j)
         if (((aanc[i] >> j) & 1ull) && (dparent[i] < 0 || nanc[j] > nanc[dparent[i]])) dparent[i] = j;
     std::vector<char> in_core(n_act, 0);
-    for (int k = 0; k < 6; ++k) in_core[k] = 1;
+    for (int k = 0; k < n_root; ++k) in_core[k] = akind[k] != 7;  // null dofs are one-row "limbs": they need no core column
     std::vector<std::vector<int>> bins;
     for (int guard = 0; guard < 64 && !sq_ok; ++guard) {
       const int nc = (int)std::count(in_core.begin(), in_core.end(), (char)1);
@@ -341,7 +352,7 @@ int build_device_model(gmr_model *m) {
       std::vector<int> comp(n_act, -1), csize, ctop;
       for (int i = 0; i < n_act; ++i) {
         if (in_core[i]) continue;
-        if (in_core[dparent[i]]) { comp[i] = (int)csize.size(); csize.push_back(1); ctop.push_back(i); }
+        if (dparent[i] < 0 || in_core[dparent[i]]) { comp[i] = (int)csize.size(); csize.push_back(1); ctop.push_back(i); }
         else { comp[i] = comp[dparent[i]]; csize[comp[i]]++; }
       }
       const int cap = 16 - nc;
@@ -409,7 +420,7 @@ int build_device_model(gmr_model *m) {
     for (int i = 0; i < n_act; ++i) {
       unsigned mk = 0;
       for (int t = 0; t < h.ntask[k]; ++t)
-        if (akind[i] < 6 || above(abody[i], tbody[k * GMR_MAX_TASKS + t])) mk |= 1u << t;
+        if (akind[i] != 6 || above(abody[i], tbody[k * GMR_MAX_TASKS + t])) mk |= 1u << t;
       auto it = ids.find(mk);
       if (it == ids.end()) {
         it = ids.emplace(mk, ncomp[k]).first;
@@ -704,6 +715,7 @@ int build_device_model(gmr_model *m) {
       same = tbody_ik[t] == tbody_ik[GMR_MAX_TASKS + t] && tslot[t] == tslot[GMR_MAX_TASKS + t];
     dm.same_tasks = same ? 1 : 0;
   }
+  dm.root_planar = root_mask == 0x23;
   dm.root_tslot = -1;  // GMR_INIT_ROOT_TARGET: the slot whose prepared target the floating base (body 0) is asked to track
   for (int k = 0; k < 2 && dm.root_tslot < 0; ++k)
     for (int t = 0; h.use_table[k] && t < h.ntask[k] && dm.root_tslot < 0; ++t)

@@ -108,8 +108,10 @@ struct DevModel {
   int nbody, nq, nv, nslot, root_slot, n_act, root_tslot, same_tasks;
   int ntask[2], use_table[2], ncomp[2], ncpass[2];  // ncpass: composite passes per table
   int npairp, fkrounds, sq_ok, sq_nlimb;              // npairp: entries of hplan (a multiple of 128)
+  int root_planar, pad_[3];                           // 1: planar base (gmr_blob.h root_dof_mask 0x23): rows 2-4 of the QP are null dofs (akind 7)
   // per active dof [64]
-  int abody[64], akind[64], aqadr[64], alimited[64];  // akind: 0..2 root translation, 3..5 root rotation, 6 hinge
+  int abody[64], akind[64], aqadr[64], alimited[64];  // akind: 0..2 root translation, 3..5 root rotation, 6 hinge, 7 null (a root
+                                                      // dof the model lacks: takes the hinge path with the root's zero axis)
   double arange[128];                                 // [64][2]
   int acomp[2 * 64];                                  // composite node of the dof per table
   // per task, table-major [2][GMR_MAX_TASKS]
@@ -1281,7 +1283,19 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
     __syncthreads();
     if (kf == 0 && w.init_row == GMR_INIT_ROOT_TARGET && m.root_tslot >= 0) {  // wave-uniform: speculative chunk start (gmr_blob.h)
       const int rts = m.root_tslot;
-      if (lane < 7) q[lane] = lane < 3 ? tp[3 * rts + lane] : tq[4 * rts + lane - 3];
+      if (m.root_planar) {  // a planar base takes the target's place and heading only
+        const double tw = tq[4 * rts], tx = tq[4 * rts + 1], ty = tq[4 * rts + 2], tz = tq[4 * rts + 3];
+        // heading (ZYX yaw) of the target as a half-angle pair, without trigonometry: (cy, sy) = (C, S) / |(C, S)|
+        const double S = 2.0 * (tw * tz + tx * ty), C = 1.0 - 2.0 * (ty * ty + tz * tz), n2 = S * S + C * C;
+        double ch = 1.0, sh = 0.0;
+        if (n2 > 1e-24) {
+          const double rn = fast_rsqrt(n2), cy = C * rn, sy = S * rn;
+          if (cy >= 0.0) { ch = fast_sqrt(0.5 * (1.0 + cy)); sh = fast_div(0.5 * sy, ch); }
+          else { sh = fast_sqrt(0.5 * (1.0 - cy)); sh = sy < 0.0 ? -sh : sh; ch = fast_div(0.5 * sy, sh); }
+        }
+        if (lane < 2) q[lane] = tp[3 * rts + lane];
+        if (lane >= 3 && lane < 7) q[lane] = lane == 3 ? ch : lane == 6 ? sh : 0.0;
+      } else if (lane < 7) q[lane] = lane < 3 ? tp[3 * rts + lane] : tq[4 * rts + lane - 3];
       __syncthreads();
     }
     GMR_STAMP(0);

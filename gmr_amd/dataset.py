@@ -29,6 +29,10 @@ from .motion_retarget import GeneralMotionRetargeting
 def motions_from_qpos(gmr: GeneralMotionRetargeting, qpos: torch.Tensor, seq_offsets: Sequence[int], fps,
                       height_adjust: bool = True, root_origin_offset: bool = True, ground_offset: float = 0.0) -> List[Dict]:
     """qpos ``[N, nq]`` float64 on the GPU (concatenated clips) -> one motion dict per clip."""
+    if gmr.model.planar_base:
+        # the dataset scripts read a free-joint root out of qpos (root_pos = qpos[:3], root_rot = qpos[3:7],
+        # scripts/smplx_to_robot_dataset.py:97-103); the reference has no such path for galaxea_r1pro either
+        raise NotImplementedError("the dataset post-processing assumes a free-joint root; use retarget_batch for a planar-base robot")
     eng = gmr._engine
     offs = np.asarray(seq_offsets, dtype=np.int64)
     N = int(qpos.shape[0])

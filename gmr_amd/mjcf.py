@@ -2,8 +2,8 @@
 
 Reads only what the retarget hot path needs from a MuJoCo XML model: the body
 tree (``pos``/``quat``), hinge ``axis``/``range``/``limited``, the free root
-joint, ``<include>``, ``<compiler angle=... autolimits=...>`` and default-class
-inheritance for joint attributes.  Inertials, geoms, meshes, actuators,
+joint (or the planar base of galaxea_r1pro: slide x, slide y, hinge z on the root body), ``<include>``,
+``<compiler angle=... autolimits=...>`` and default-class inheritance for joint attributes.  Inertials, geoms, meshes, actuators,
 sensors and keyframes are ignored.
 
 It replaces two reference loaders at once:
@@ -32,6 +32,9 @@ import numpy as np
 JNT_NONE = 0
 JNT_HINGE = 1
 JNT_FREE = 2
+
+ROOT_DOFS_FREE = 0x3F    # x y z rx ry rz
+ROOT_DOFS_PLANAR = 0x23  # x y . . . rz -- a mobile base written as slide x + slide y + hinge z on the root body
 
 
 class MjcfError(ValueError):
@@ -73,8 +76,55 @@ class RobotModel:
     nv: int
     timestep: float
     angle_unit: str
+    # Which of the root's six free-joint dofs exist.  Internally every robot carries a free-joint root (``nq = 7 + hinges``): a
+    # planar base is that joint with z / roll / pitch taken out of the IK (ROOT_DOFS_PLANAR), and ``to_mj_qpos`` / ``from_mj_qpos``
+    # translate to MuJoCo's ``[x, y, yaw, hinges]``.
+    root_dofs: int = ROOT_DOFS_FREE
+    root_jnt_names: Optional[List[str]] = None
 
     # ------------------------------------------------------------------
+    @property
+    def planar_base(self) -> bool:
+        return self.root_dofs == ROOT_DOFS_PLANAR
+
+    @property
+    def mj_nq(self) -> int:
+        """``mujoco.MjModel.nq`` of the XML: 3 instead of 7 coordinates for a planar base."""
+        return self.nq - 4 if self.planar_base else self.nq
+
+    @property
+    def mj_nv(self) -> int:
+        return self.nv - 3 if self.planar_base else self.nv
+
+    def to_mj_qpos(self, q, yaw_ref=None):
+        """Internal ``[..., nq]`` -> the XML's qpos layout (numpy or torch; identity for a free root).  A planar base gives
+        ``[x - x0, y - y0, yaw, hinges]``; ``yaw_ref`` (the previous frame's yaw, same leading shape) picks the branch of the
+        angle nearest to it -- MuJoCo's hinge coordinate accumulates, a quaternion does not."""
+        if not self.planar_base:
+            return q
+        import math
+        xp = __import__("torch") if type(q).__module__.startswith("torch") else np
+        yaw = 2.0 * xp.arctan2(q[..., 6], q[..., 3])
+        yaw = xp.where(yaw > math.pi, yaw - 2 * math.pi, xp.where(yaw <= -math.pi, yaw + 2 * math.pi, yaw))
+        if yaw_ref is not None:
+            yaw = yaw + 2 * math.pi * xp.round((yaw_ref - yaw) / (2 * math.pi))
+        head = xp.stack([q[..., 0] - float(self.body_pos[0, 0]), q[..., 1] - float(self.body_pos[0, 1]), yaw], -1)
+        return xp.concatenate([head, q[..., 7:]], -1) if xp is np else xp.cat([head, q[..., 7:]], -1)
+
+    def from_mj_qpos(self, q):
+        """The XML's qpos layout -> internal (numpy)."""
+        if not self.planar_base:
+            return np.asarray(q, dtype=np.float64)
+        q = np.asarray(q, dtype=np.float64)
+        out = np.zeros(q.shape[:-1] + (self.nq,))
+        out[..., 0] = q[..., 0] + self.body_pos[0, 0]
+        out[..., 1] = q[..., 1] + self.body_pos[0, 1]
+        out[..., 2] = self.body_pos[0, 2]
+        out[..., 3] = np.cos(0.5 * q[..., 2])
+        out[..., 6] = np.sin(0.5 * q[..., 2])
+        out[..., 7:] = q[..., 3:]
+        return out
+
     @property
     def nbody(self) -> int:
         return len(self.body_names)
@@ -149,8 +199,9 @@ class RobotModel:
                     "joint": None
                     if self.jnt_type[b] == JNT_NONE
                     else {
-                        "type": "free" if self.jnt_type[b] == JNT_FREE else "hinge",
+                        "type": ("planar" if self.planar_base else "free") if self.jnt_type[b] == JNT_FREE else "hinge",
                         "name": self.jnt_names[b],
+                        **({"names": list(self.root_jnt_names or [])} if self.jnt_type[b] == JNT_FREE and self.planar_base else {}),
                         "axis": [float(x) for x in self.jnt_axis_raw[b]],
                         "range": [float(x) for x in self.jnt_range[b]],
                         "limited": bool(self.jnt_limited[b]),
@@ -173,7 +224,9 @@ class RobotModel:
                     parent=b["parent"],
                     pos=np.asarray(b["pos"], dtype=np.float64),
                     quat=np.asarray(b["quat"], dtype=np.float64),
-                    jtype=JNT_NONE if j is None else (JNT_FREE if j["type"] == "free" else JNT_HINGE),
+                    jtype=JNT_NONE if j is None else (JNT_FREE if j["type"] in ("free", "planar") else JNT_HINGE),
+                    root_dofs=ROOT_DOFS_PLANAR if j is not None and j["type"] == "planar" else ROOT_DOFS_FREE,
+                    root_names=None if j is None or j["type"] != "planar" else list(j.get("names", [])),
                     jname=None if j is None else j["name"],
                     axis=np.zeros(3) if j is None else np.asarray(j["axis"], dtype=np.float64),
                     rng=np.zeros(2) if j is None else np.asarray(j["range"], dtype=np.float64),
@@ -194,6 +247,8 @@ class _BodyRec:
     axis: np.ndarray
     rng: np.ndarray
     limited: bool
+    root_dofs: int = ROOT_DOFS_FREE
+    root_names: Optional[List[str]] = None
 
 
 def _floats(s: str, n: int, what: str) -> np.ndarray:
@@ -292,7 +347,24 @@ def load_mjcf(path: str, name: Optional[str] = None) -> RobotModel:
         quat = _floats(node.attrib.get("quat", "1 0 0 0"), 4, "body quat")
         joints = [(j, True) for j in node.findall("freejoint")] + [(j, False) for j in node.findall("joint")]
         jtype, jname, axis, rng, limited = JNT_NONE, None, np.zeros(3), np.zeros(2), False
-        if len(joints) > 1:
+        root_dofs, root_names = ROOT_DOFS_FREE, None
+        if parent == -1 and len(joints) == 3 and not any(f for _, f in joints):
+            # a planar mobile base (assets/galaxea_r1pro/r1_pro.xml:102-104): slide x, slide y, hinge z, in this order, unlimited
+            want = [("slide", (1.0, 0.0, 0.0)), ("slide", (0.0, 1.0, 0.0)), ("hinge", (0.0, 0.0, 1.0))]
+            root_names = []
+            for (jel, _), (typ, ax) in zip(joints, want):
+                attrs = defaults.joint_attrs(jel, childclass)
+                a = _floats(attrs.get("axis", "0 0 1"), 3, "joint axis")
+                lim = attrs.get("limited", "auto")
+                if attrs.get("type", "hinge") != typ or tuple(a) != ax or "range" in attrs or lim == "true" or \
+                        np.any(_floats(attrs.get("pos", "0 0 0"), 3, "joint pos") != 0.0) or float(attrs.get("ref", 0.0)) != 0.0:
+                    raise MjcfError("root body with three joints: only slide x, slide y, hinge z (unlimited, at the body origin) is supported")
+                root_names.append(attrs.get("name"))
+            if np.any(quat != np.array([1.0, 0.0, 0.0, 0.0])):
+                raise MjcfError("planar base: the root body must not be rotated")
+            jtype, jname, root_dofs = JNT_FREE, root_names[0], ROOT_DOFS_PLANAR
+            joints = []
+        elif len(joints) > 1:
             raise MjcfError(f"body {node.attrib.get('name')}: {len(joints)} joints on one body not supported")
         if joints:
             jel, is_freejoint = joints[0]
@@ -326,10 +398,10 @@ def load_mjcf(path: str, name: Optional[str] = None) -> RobotModel:
                     limited = bool(autolimits and "range" in attrs and rng[0] < rng[1])
             else:
                 raise MjcfError(f"joint {jname}: type {typ!r} not supported (hinge/free only)")
-        elif parent == -1:
+        elif parent == -1 and jtype != JNT_FREE:
             raise MjcfError("robot root must carry a free joint")
         idx = len(recs)
-        recs.append(_BodyRec(node.attrib.get("name", f"body{idx}"), parent, pos, quat, jtype, jname, axis, rng, limited))
+        recs.append(_BodyRec(node.attrib.get("name", f"body{idx}"), parent, pos, quat, jtype, jname, axis, rng, limited, root_dofs, root_names))
         for child in node.findall("body"):
             add_body(child, idx, childclass)
 
@@ -373,7 +445,7 @@ def _assemble(name: str, source: str, recs: List[_BodyRec], timestep: float, ang
         name=name, source=source, body_names=[r.name for r in recs], parent=parent, body_pos=pos,
         body_quat=quat, body_quat_raw=quat_raw, jnt_type=jtype, jnt_axis=axis, jnt_axis_raw=axis_raw,
         jnt_range=rng, jnt_limited=limited, jnt_names=[r.jname for r in recs], qpos_adr=qadr, dof_adr=dadr,
-        nq=nq, nv=nv, timestep=timestep, angle_unit=angle_unit,
+        nq=nq, nv=nv, timestep=timestep, angle_unit=angle_unit, root_dofs=recs[0].root_dofs, root_jnt_names=recs[0].root_names,
     )
 
 

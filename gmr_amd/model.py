@@ -115,6 +115,9 @@ def compile_model(robot: RobotModel, config: Optional[IKConfig], actual_human_he
             if len(tab) > MAX_TASKS:
                 raise NotImplementedError("too many tasks")
         off1: Dict[str, IKTask] = {t.human: t for t in tabs[0]}  # pos_offsets1 / rot_offsets1, :90-94
+        # a table that is switched off is never given targets nor solved (:132,163): its frames need not even exist in the robot
+        # (smplx_to_r1pro.json's table 2 names G1 links), so it contributes no tasks -- only table 1's offsets above
+        tabs = [tab if on else [] for tab, on in zip(tabs, (config.use_ik_match_table1, config.use_ik_match_table2))]
         for name in scale.keys():
             (slot_names if name in off1 else unoffset).append(name)
         if config.human_root_name not in scale:
@@ -178,7 +181,8 @@ def compile_model(robot: RobotModel, config: Optional[IKConfig], actual_human_he
     header = struct.pack(
         _HEADER_FMT,
         BLOB_MAGIC, BLOB_VERSION, total, 0,
-        nb, robot.nq, robot.nv, len(slot_names), len(tasks[0]), len(tasks[1]), use[0], use[1], root_slot, 0, 0, 0,
+        nb, robot.nq, robot.nv, len(slot_names), len(tasks[0]), len(tasks[1]), use[0], use[1], root_slot,
+        0 if robot.root_dofs == 0x3F else int(robot.root_dofs), 0, 0,
         offs["parent"], offs["jnt_type"], offs["qpos_adr"], offs["dof_adr"], offs["jnt_limited"],
         offs["body_pos"], offs["body_quat"], offs["body_quat_raw"], offs["jnt_axis"], offs["jnt_range"], offs["qpos0"],
         offs["slot_scale"], offs["slot_pos_off"], offs["slot_rot_off"], offs["slot_is_foot"],

@@ -35,7 +35,7 @@ class _Data:
 
     @property
     def qpos(self) -> np.ndarray:
-        return self._o._qpos.copy()
+        return self._o._caller_qpos().copy()
 
     @property
     def xpos(self) -> np.ndarray:
@@ -157,7 +157,8 @@ class GeneralMotionRetargeting:
     # ------------------------------------------------------------------ state
     def setup_retarget_configuration(self):
         """Reset to ``qpos0`` (what a fresh ``mink.Configuration(model)`` holds, :75)."""
-        self._qpos = np.array(self.model.qpos0, dtype=np.float64)  # the current configuration (host copy)
+        self._qpos = np.array(self.model.qpos0, dtype=np.float64)  # the current configuration (host copy, free-joint layout)
+        self._yaw = 0.0  # planar base only: the accumulated heading MuJoCo's hinge coordinate would hold (RobotModel.to_mj_qpos)
         self.configuration = _Configuration(self)
         self.scaled_human_data = None
         self._last_pos_np = None
@@ -170,6 +171,31 @@ class GeneralMotionRetargeting:
     @property
     def _state(self) -> torch.Tensor:
         return torch.from_numpy(self._qpos).to(self.device).reshape(1, -1)
+
+    def _caller_qpos(self) -> np.ndarray:
+        """The current configuration in the XML's own qpos layout: ``[x, y, z, qw..qz, hinges]`` for a free-joint root (the
+        engine's layout), ``[x, y, yaw, hinges]`` for the planar base of galaxea_r1pro."""
+        if not self.model.planar_base:
+            return self._qpos
+        return self.model.to_mj_qpos(self._qpos, yaw_ref=np.float64(self._yaw))
+
+    def _caller_layout_batch(self, out: torch.Tensor, offs: np.ndarray) -> torch.Tensor:
+        """``[N, nq]`` engine output -> the XML's layout; a planar base's heading is unwrapped along every clip from its first
+        frame's principal value (the hinge coordinate of the reference accumulates from ``qpos0``'s 0)."""
+        if not self.model.planar_base or out.shape[0] == 0:
+            return out
+        mj = self.model.to_mj_qpos(out)
+        yaw = mj[:, 2]
+        jump = torch.round((yaw[1:] - yaw[:-1]) / (2 * np.pi))
+        starts = torch.as_tensor(np.asarray(offs[:-1], dtype=np.int64), device=out.device)
+        starts = starts[starts < out.shape[0]]
+        inner = starts[starts > 0]
+        jump[inner - 1] = 0  # no unwrapping across a clip boundary
+        c = torch.cat([torch.zeros(1, dtype=yaw.dtype, device=yaw.device), torch.cumsum(jump, 0)])
+        lens = torch.diff(torch.cat([starts, torch.tensor([out.shape[0]], device=out.device)]))
+        base = torch.repeat_interleave(c[starts], lens)
+        mj[:, 2] = yaw - 2 * np.pi * (c - base)
+        return mj
 
     def _session(self, names: Sequence[str]):
         """The live session for this frame layout; the warm start follows the object, not the session."""
@@ -224,7 +250,9 @@ class GeneralMotionRetargeting:
         if not np.all(np.isfinite(q)):
             raise FloatingPointError("retarget produced non-finite qpos")
         self._qpos = q
-        return q.copy()
+        if self.model.planar_base:
+            self._yaw = float(self.model.to_mj_qpos(q, yaw_ref=np.float64(self._yaw))[2])
+        return self._caller_qpos().copy()
 
     def _evaluate(self, want_task_errors: bool):
         if getattr(self, "_last_pos_np", None) is None:
@@ -275,7 +303,8 @@ class GeneralMotionRetargeting:
         from ._native import INIT_QPOS0, INIT_ROOT_TARGET
         clip_init = INIT_ROOT_TARGET if clip_start == "root_target" else INIT_QPOS0
         cols = self._columns(list(body_names))  # KeyError where the reference raises
-        if is_np and isinstance(quat, np.ndarray) and chunk == 0 and clip_init == INIT_QPOS0 and pos.ndim == 3 and pos.shape[0] >= self.HOST_PIPELINE_MIN_FRAMES:
+        if is_np and isinstance(quat, np.ndarray) and chunk == 0 and clip_init == INIT_QPOS0 and pos.ndim == 3 and pos.shape[0] >= self.HOST_PIPELINE_MIN_FRAMES \
+                and not self.model.planar_base:
             # big host batches: two streams, copies overlapped with the kernel, pinned result (Engine.ik_solve_host)
             N = int(pos.shape[0])
             offs = np.asarray([0, N] if seq_offsets is None else seq_offsets, dtype=np.int64)
@@ -321,6 +350,7 @@ class GeneralMotionRetargeting:
                 raise FloatingPointError("retarget_batch produced non-finite qpos")
             if bad[1]:
                 raise RuntimeError("a box QP hit its iteration cap (the reference would assert on a failed QP)")
+        out = self._caller_layout_batch(out, offs)
         if is_np:
             out = out.cpu().numpy()
             iters = iters.cpu().numpy() if iters is not None else None

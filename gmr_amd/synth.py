@@ -113,6 +113,9 @@ def synth_robot_trajectory(robot: RobotModel, T: int, rng: np.random.Generator, 
     qpos[:, 0:2] = xy
     qpos[:, 2] = z
     qpos[:, 3:7] = qmul(qmul(qy, qp), qr)
+    if robot.planar_base:  # a mobile base drives in the plane: fixed height, heading only (same random draws as above)
+        qpos[:, 2] = robot.body_pos[0, 2]
+        qpos[:, 3:7] = qy
     return qpos
 
 

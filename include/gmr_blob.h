@@ -43,7 +43,10 @@ typedef struct gmr_blob_header {
   int32_t ntask[2];   /* tasks with non-zero weight in table 1 / table 2       */
   int32_t use_table[2];
   int32_t root_slot;  /* slot of human_root_name                               */
-  int32_t reserved1[3];
+  int32_t root_dof_mask; /* which of the root's free-joint dofs (x y z rx ry rz, bit k = dof k) the IK may move; 0 = all six.
+                          * 0x23 = a planar base (slide x, slide y, hinge z on the root body; assets/galaxea_r1pro/r1_pro.xml:102-104):
+                          * qpos keeps the free-joint layout, z / roll / pitch simply never change                                */
+  int32_t reserved1[2];
 
   /* byte offsets from the start of the blob */
   uint32_t off_parent;        /* int32 [nbody]                                 */

@@ -564,6 +564,15 @@ void oracle_build_qp(const oracle_model *m, int tab, const gmr_ik_params *prm, c
       }
     }
   }
+  /* a root that is not a full free joint (gmr_blob.h root_dof_mask; the planar base of assets/galaxea_r1pro/r1_pro.xml:102-104):
+   * the reference's model simply has no such dofs, i.e. its H is the sub-matrix without them.  Decoupling them here (zero row,
+   * column and gradient, diagonal = the damping) solves that sub-problem exactly and leaves dq = 0 on the absent dofs. */
+  if (m->h.root_dof_mask)
+    for (int k = 0; k < 6; k++)
+      if (!((m->h.root_dof_mask >> k) & 1)) {
+        for (int l = 0; l < nv; l++) H[k * nv + l] = H[l * nv + k] = 0.0;
+        c[k] = 0.0;
+      }
   for (int k = 0; k < nv; k++) H[k * nv + k] += diag;
   (void)tp; (void)tq;
   for (int k = 0; k < nv; k++) { lo[k] = -1e30; hi[k] = 1e30; }
@@ -618,7 +627,17 @@ int oracle_retarget_frame_ex(const oracle_model *m, const gmr_ik_params *prm, do
   oracle_prepare_targets_scaled(m, hp, hq, prm->offset_to_ground, hscale, tp, tq);
   if (init_root) {
     int rts = root_target_slot(m);
-    if (rts >= 0) { memcpy(qpos, tp + 3 * rts, 3 * sizeof(double)); memcpy(qpos + 3, tq + 4 * rts, 4 * sizeof(double)); }
+    if (rts >= 0 && m->h.root_dof_mask == 0x23) { /* planar base: the target's place and heading only */
+      const double *t = tq + 4 * rts;
+      double S = 2.0 * (t[0] * t[3] + t[1] * t[2]), C = 1.0 - 2.0 * (t[2] * t[2] + t[3] * t[3]), n2 = S * S + C * C, ch = 1.0, sh = 0.0;
+      if (n2 > 1e-24) { /* ZYX yaw as a half-angle pair */
+        double cy = C / sqrt(n2), sy = S / sqrt(n2);
+        if (cy >= 0.0) { ch = sqrt(0.5 * (1.0 + cy)); sh = 0.5 * sy / ch; }
+        else { sh = sqrt(0.5 * (1.0 - cy)); if (sy < 0.0) sh = -sh; ch = 0.5 * sy / sh; }
+      }
+      qpos[0] = tp[3 * rts]; qpos[1] = tp[3 * rts + 1];
+      qpos[3] = ch; qpos[4] = 0.0; qpos[5] = 0.0; qpos[6] = sh;
+    } else if (rts >= 0) { memcpy(qpos, tp + 3 * rts, 3 * sizeof(double)); memcpy(qpos + 3, tq + 4 * rts, 4 * sizeof(double)); }
   }
   for (int tab = 0; tab < 2; tab++) {
     if (!m->h.use_table[tab]) continue;

@@ -721,3 +721,37 @@ def test_bvh_folder_to_robot_batch(golden_dir, tmp_path):
         assert float((q[a:b] - q1).abs().max().item()) < 1e-9
     with pytest.raises(ValueError):
         load_lafan1_files([files[0], os.path.join(golden_dir, "bvh_canonical_40f.bvh")])   # another skeleton
+
+
+def test_planar_base_robot_through_the_class():
+    """GMR("smplx", "galaxea_r1pro") -- reachable in the reference through scripts/smplx_to_robot.py:29 -- returns MuJoCo's own
+    qpos layout [x, y, yaw, 24 hinges]: per-frame calls, the batched call and the oracle agree, and the heading accumulates past
+    +-pi like a hinge coordinate instead of wrapping like a quaternion."""
+    from gmr_amd import GeneralMotionRetargeting as GMR
+    g = GMR("smplx", "galaxea_r1pro")
+    cm = g._cm
+    assert g.model.mj_nq == 27 and g.configuration.data.qpos.shape == (27,) and len(g.tasks1) == 10 and len(g.tasks2) == 0
+    pos, quat, names, offs, q_true = synth.synth_clips(cm, 2, 90, seed=12, hard=False, dtype=np.float64)
+    # spin the second clip's targets about z so that the base turns through more than a full revolution
+    T = 90
+    ang = np.linspace(0.0, 2.6 * np.pi, T)
+    c, s_ = np.cos(ang), np.sin(ang)
+    p2 = pos[T:].copy()
+    pos[T:, :, 0], pos[T:, :, 1] = c[:, None] * p2[:, :, 0] - s_[:, None] * p2[:, :, 1], s_[:, None] * p2[:, :, 0] + c[:, None] * p2[:, :, 1]
+    spin = np.stack([np.cos(ang / 2), 0 * ang, 0 * ang, np.sin(ang / 2)], -1)
+    quat[T:] = synth.qmul(np.broadcast_to(spin[:, None], quat[T:].shape), quat[T:])
+    qb = g.retarget_batch(pos, quat, names, seq_offsets=offs)
+    assert qb.shape == (2 * T, 27)
+    q_ref, _, _ = Oracle(cm.blob).ik_solve(pos, quat, cm.slot_columns(names), make_items(offs))
+    mj_ref = cm.robot.to_mj_qpos(q_ref)
+    assert np.abs(qb[:, :2] - mj_ref[:, :2]).max() < 1e-6 and np.abs(qb[:, 3:] - mj_ref[:, 3:]).max() < 1e-6
+    assert np.abs(np.angle(np.exp(1j * (qb[:, 2] - mj_ref[:, 2])))).max() < 1e-6          # same heading ...
+    assert np.abs(np.diff(qb[T:, 2])).max() < 1.0 and qb[-1, 2] - qb[T, 2] > 2 * np.pi       # ... accumulated, not wrapped
+    assert np.abs(np.diff(qb[:T, 2])).max() < 1.0
+    for f in range(T, 2 * T):  # the stateful per-frame API walks the same path
+        q = g.retarget({n: (pos[f, i], quat[f, i]) for i, n in enumerate(names)})
+        assert q.shape == (27,) and np.abs(q - qb[f]).max() < 1e-6, f
+    assert np.abs(g.configuration.data.qpos - qb[-1]).max() < 1e-6 and g.configuration.data.xpos.shape == (26, 3)
+    from gmr_amd import dataset
+    with pytest.raises(NotImplementedError):
+        dataset.retarget_clips(g, pos, quat, names, offs)

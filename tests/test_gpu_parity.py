@@ -99,6 +99,26 @@ def test_ik_matches_oracle_other_registry_robots(robot, dev):
     assert _qpos_diff(q.cpu().numpy(), q_ref) < 1e-6 and np.array_equal(it.cpu().numpy(), it_ref)
 
 
+@pytest.mark.parametrize("hard", [False, True])
+@pytest.mark.parametrize("qp", ["structured", "generic"])
+def test_planar_base_robot_matches_oracle(hard, qp, dev, monkeypatch):
+    """galaxea_r1pro: slide x + slide y + hinge z base, one IK stage (table 2 switched off), wheels without
+    tasks.  The kernel drops z / roll / pitch from the QP (gmr_blob.h root_dof_mask); result == the oracle's reduced problem."""
+    monkeypatch.setenv("GMR_AMD_GENERIC_QP", "1" if qp == "generic" else "0")
+    cm = compiled("smplx", "galaxea_r1pro")
+    eng, orc = _engine(cm), Oracle(cm.blob)
+    assert eng.info.n_active_dof == 6 + 4 + 14 and (eng.info.reserved[0] == 0) == (qp == "generic")
+    pos, quat, names, offs, _ = synth.synth_clips(cm, 3, 60, seed=8, hard=hard, dtype=np.float32)
+    sc = cm.slot_columns(names)
+    from gmr_amd._native import INIT_ROOT_TARGET
+    for items in (make_items(offs), make_items(offs, clip_init=INIT_ROOT_TARGET)):
+        q_ref, it_ref, _ = orc.ik_solve(pos, quat, sc, items)
+        q, it, _ = eng.ik_solve(torch.from_numpy(pos).to(dev), torch.from_numpy(quat).to(dev), sc, items)
+        q, it = q.cpu().numpy(), it.cpu().numpy()
+        assert (it >> 30).max() == 0 and _qpos_diff(q, q_ref) < 1e-6 and np.array_equal(it, it_ref)
+        assert np.all(q[:, 2] == cm.robot.body_pos[0, 2]) and not q[:, 4:6].any() and not q[:, 7:13].any()  # z, roll / pitch, wheels
+
+
 def _synthetic_robot(tmp_path, limbs, with_tasks_per_limb, jrange="-1.2 1.4", table2_reversed=False):
     """A floating base with `limbs` chains of hinges (list of chain lengths) hanging off it; tasks on the base and on every
     `with_tasks_per_limb`-th link of each chain.  Returns a compiled model."""

@@ -34,7 +34,7 @@ def test_expected_sizes(robot):
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
-@pytest.mark.parametrize("robot", sorted(set(params._ROBOT_XML_REL) - {"galaxea_r1pro"}))
+@pytest.mark.parametrize("robot", sorted(params._ROBOT_XML_REL))
 def test_packs_are_fresh(robot, monkeypatch):
     """The shipped packs equal what the MJCF compiler produces from the reference's XML today."""
     monkeypatch.delenv("GMR_ROOT", raising=False)
@@ -43,6 +43,35 @@ def test_packs_are_fresh(robot, monkeypatch):
     assert pack.body_names == xml.body_names
     for f in ("parent", "body_pos", "body_quat_raw", "jnt_type", "jnt_axis_raw", "jnt_range", "jnt_limited", "qpos_adr"):
         np.testing.assert_array_equal(getattr(pack, f), getattr(xml, f))
+    assert pack.root_dofs == xml.root_dofs and pack.root_jnt_names == xml.root_jnt_names
+
+
+def test_planar_base_model_and_qpos_layout(tmp_path):
+    """galaxea_r1pro (assets/galaxea_r1pro/r1_pro.xml:102-104): slide x + slide y + hinge z on the root body is carried as a
+    free-joint root whose z / roll / pitch never move; MuJoCo's own layout [x, y, yaw, hinges] is a view of it."""
+    from gmr_amd.mjcf import ROOT_DOFS_PLANAR
+    rob = compiled("smplx", "galaxea_r1pro").robot
+    assert rob.planar_base and rob.root_dofs == ROOT_DOFS_PLANAR and rob.root_jnt_names == ["base_x", "base_y", "base_yaw"]
+    assert (rob.nbody, rob.nq, rob.nv, rob.mj_nq, rob.mj_nv) == (25, 31, 30, 27, 27)
+    assert not rob.jnt_limited[rob.body_index("wheel_motor_link1")] and rob.jnt_limited[rob.body_index("steer_motor_link1")]
+    cm = compiled("smplx", "galaxea_r1pro")
+    assert len(cm.tasks[0]) == 10 and len(cm.tasks[1]) == 0  # table 2 is switched off (and names another robot's links)
+    rng = np.random.default_rng(0)
+    mj = np.concatenate([rng.normal(size=(50, 2)), rng.uniform(-3.1, 3.1, (50, 1)), rng.normal(size=(50, 24))], axis=1)
+    q = rob.from_mj_qpos(mj)
+    assert q.shape == (50, 31) and np.all(q[:, 2] == rob.body_pos[0, 2]) and not q[:, 4:6].any()
+    np.testing.assert_allclose(rob.to_mj_qpos(q), mj, atol=1e-12)
+    import torch
+    np.testing.assert_allclose(rob.to_mj_qpos(torch.from_numpy(q)).numpy(), mj, atol=1e-12)
+    # the hinge coordinate accumulates: the branch nearest to the previous frame's value
+    far = rob.to_mj_qpos(rob.from_mj_qpos(np.array([[0.0, 0.0, 3.0] + [0.0] * 24])), yaw_ref=np.array([3.0 + 4 * np.pi]))
+    assert abs(far[0, 2] - (3.0 + 4 * np.pi)) < 1e-12
+    # anything else on a root body is still refused
+    p = tmp_path / "m.xml"
+    p.write_text('<mujoco><compiler angle="radian"/><worldbody><body name="a"><joint type="slide" axis="1 0 0"/>'
+                 '<joint type="slide" axis="0 1 0"/><joint type="hinge" axis="0 1 0"/></body></worldbody></mujoco>')
+    with pytest.raises(MjcfError):
+        load_mjcf(str(p))
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")

@@ -371,3 +371,25 @@ def test_reference_error_logs_plateau(golden_dir):
         att = __import__("json").load(f)
     assert abs(att["default_flags_on_dumped_frame"][0][0] - e1s[0]) < 1e-9  # the committed attempt table is this oracle's
     assert min(c[0]["worst_rel_miss"][k] for k, c in att["closest"].items()) > 0.05  # ... and records that nothing matched
+
+
+def test_planar_base_is_the_reduced_problem():
+    """galaxea_r1pro: the oracle decouples the three root dofs the model does not have (gmr_blob.h root_dof_mask).  The step it
+    takes must be the solution of the reference's 27-dof problem -- H and c without those rows / columns -- and z, roll, pitch,
+    the wheels (no task below them) never move."""
+    cm = compiled("smplx", "galaxea_r1pro")
+    orc = Oracle(cm.blob)
+    pos, quat, names, offs, _ = synth.synth_clips(cm, 1, 40, seed=3, hard=True, dtype=np.float64)
+    sc = cm.slot_columns(names)
+    q, it, _ = orc.ik_solve(pos, quat, sc, make_items(offs, WORK_ITEM_DTYPE))
+    assert np.all(q[:, 2] == cm.robot.body_pos[0, 2]) and not q[:, 4:6].any() and not q[:, 7:13].any()
+    assert np.abs(np.linalg.norm(q[:, 3:7], axis=1) - 1).max() < 1e-12 and it.min() >= 1 and it.max() <= 11  # one stage only
+    # one solve by hand on the reduced system
+    tp, tq = orc.prepare_targets(pos[5][sc], quat[5][sc])
+    H, c, lo, hi = orc.build_qp(0, q[4], tp, tq)
+    keep = np.array([0, 1, 5] + list(range(6, cm.robot.nv)))
+    drop = np.array([2, 3, 4])
+    assert not H[np.ix_(drop, keep)].any() and not c[drop].any() and np.all(np.diag(H)[drop] > 0)
+    dq, _ = box_qp(H, c, lo, hi)
+    dq_red, _ = box_qp(np.ascontiguousarray(H[np.ix_(keep, keep)]), c[keep].copy(), lo[keep].copy(), hi[keep].copy())
+    assert not dq[drop].any() and np.abs(dq[keep] - dq_red).max() < 1e-12
