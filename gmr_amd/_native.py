@@ -26,7 +26,7 @@ INIT_QPOS0, INIT_ROOT_TARGET = -1, -2
 
 EXPORTS = ["gmr_abi_version", "gmr_model_create", "gmr_model_destroy", "gmr_last_error", "gmr_model_info_get",
            "gmr_ik_solve", "gmr_fk", "gmr_fk_min_height", "gmr_bvh_fk", "gmr_bvh_parse_header", "gmr_bvh_parse_motion", "gmr_evaluate", "gmr_smplx_keypoints",
-           "gmr_session_create", "gmr_session_destroy", "gmr_session_reset", "gmr_session_step", "gmr_session_state",
+           "gmr_session_create", "gmr_session_destroy", "gmr_session_reset", "gmr_session_step", "gmr_session_state", "gmr_session_set_persistent",
            "gmr_group_create", "gmr_group_destroy", "gmr_group_size", "gmr_group_model", "gmr_group_last_error", "gmr_group_ik_solve"]
 
 
@@ -132,5 +132,7 @@ def load():
     L.gmr_session_step.argtypes = [vp, vp, vp, C.c_int, vp, vp]
     L.gmr_session_state.restype = C.c_int
     L.gmr_session_state.argtypes = [vp, vp]
+    L.gmr_session_set_persistent.restype = C.c_int
+    L.gmr_session_set_persistent.argtypes = [vp, C.c_int]
     _lib = L
     return L

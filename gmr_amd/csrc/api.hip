@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <numeric>
@@ -55,6 +56,12 @@ struct gmr_session {
   uint8_t *dev = nullptr;    // [qpos state (nq doubles) | work item | slot_col]
   size_t pos_bytes = 0, quat_bytes = 0, quat_off = 0, out_off = 0;
   gmr::IkLaunch L{};
+  // persistent mode (gmr_session_set_persistent): a resident wavefront fed through a pinned mailbox
+  gmr::IkSessionBox *box = nullptr;        // inside `host`
+  gmr::IkSessionBox *box_dev = nullptr;    // its device address
+  gmr::IkGroupEntry *entries = nullptr;    // device: the one-frame work item with offset_to_ground = 0 / 1
+  int idle_ms = 0;                         // 0 = one launch per frame
+  unsigned seq = 0, gen = 0;               // frames posted; resident wavefronts launched (alive: box->exited_gen != gen)
 };
 
 // Several models built for one kernel variant (gmr_group_*).
@@ -168,6 +175,17 @@ void launch_ik_group(const gmr_group *g, const gmr::IkGroupEntry *entries, const
 #endif
 }
 
+
+template <int NVP>
+void launch_ik_session(const gmr_model *m, const gmr::IkGroupEntry *entries, gmr::IkSessionBox *box, unsigned long long idle_ticks,
+                       unsigned max_polls, unsigned max_frames, unsigned gen, hipStream_t st) {
+  if (m->dm.sq_ok && !m->force_generic)
+    hipLaunchKernelGGL((gmr::ik_session_kernel<NVP, true>), dim3(1), dim3(64), m->lds_bytes, st, entries, box, idle_ticks, max_polls, max_frames, gen);
+#ifndef GMR_IK_DEV_ONLY36
+  else
+    hipLaunchKernelGGL((gmr::ik_session_kernel<NVP, false>), dim3(1), dim3(64), m->lds_bytes, st, entries, box, idle_ticks, max_polls, max_frames, gen);
+#endif
+}
 
 int build_device_model(gmr_model *m) {
   const gmr_blob_header &h = m->h;
@@ -1105,13 +1123,15 @@ gmr_session *gmr_session_create(gmr_model *m, int in_dtype, int n_cols, const in
   s->pos_bytes = (size_t)n_cols * 3 * elt; s->quat_bytes = (size_t)n_cols * 4 * elt;
   s->quat_off = (s->pos_bytes + 15) & ~size_t(15);
   s->out_off = (s->quat_off + s->quat_bytes + 15) & ~size_t(15);
-  const size_t host_bytes = s->out_off + (nq + 1) * 8;
-  if ((e = hipHostMalloc(reinterpret_cast<void **>(&s->host), host_bytes, hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc", e);
+  const size_t box_off = (s->out_off + (nq + 1) * 8 + 63) & ~size_t(63);
+  const size_t host_bytes = box_off + sizeof(gmr::IkSessionBox);
+  if ((e = hipHostMalloc(reinterpret_cast<void **>(&s->host), host_bytes, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return fail("hipHostMalloc", e);
   memset(s->host, 0, host_bytes);
   void *host_dev = nullptr;
   if ((e = hipHostGetDevicePointer(&host_dev, s->host, 0)) != hipSuccess) return fail("hipHostGetDevicePointer", e);
   const size_t item_off = (nq * 8 + 15) & ~size_t(15), col_off = item_off + sizeof(gmr_work_item);
-  if ((e = hipMalloc(reinterpret_cast<void **>(&s->dev), col_off + sizeof(int32_t) * (size_t)m->h.nslot)) != hipSuccess) return fail("hipMalloc", e);
+  const size_t ent_off = (col_off + sizeof(int32_t) * (size_t)m->h.nslot + 15) & ~size_t(15);
+  if ((e = hipMalloc(reinterpret_cast<void **>(&s->dev), ent_off + 2 * sizeof(gmr::IkGroupEntry))) != hipSuccess) return fail("hipMalloc", e);
   gmr_work_item w{};
   w.frame_begin = 0; w.n_burn = 0; w.n_out = 1; w.init_row = 0; w.final_row = 0; w.burn_row = -1; w.height_scale = 1.0;
   if ((e = hipMemcpy(s->dev + item_off, &w, sizeof(w), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
@@ -1125,13 +1145,32 @@ gmr_session *gmr_session_create(gmr_model *m, int in_dtype, int n_cols, const in
   L.qout = reinterpret_cast<double *>(hd + s->out_off); L.iters = reinterpret_cast<int *>(hd + s->out_off + nq * 8);
   L.in_f64 = in_dtype == GMR_DTYPE_F64; L.n_cols = n_cols; L.n_items = 1; L.prm = *params;
   L.dbg = nullptr;
+  s->box = reinterpret_cast<gmr::IkSessionBox *>(s->host + box_off);
+  s->box_dev = reinterpret_cast<gmr::IkSessionBox *>(hd + box_off);
+  s->entries = reinterpret_cast<gmr::IkGroupEntry *>(s->dev + ent_off);
+  gmr::IkGroupEntry ent[2];
+  for (int k = 0; k < 2; ++k) {
+    ent[k] = gmr::IkGroupEntry{};
+    ent[k].m = m->dm_dev; ent[k].L = L; ent[k].L.prm.offset_to_ground = k; ent[k].lay = m->lay;
+  }
+  if ((e = hipMemcpy(s->entries, ent, sizeof(ent), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
   if (gmr_session_reset(s, nullptr) != GMR_OK) { gmr_session_destroy(s); return nullptr; }
   return s;
+}
+
+// Persistent mode: ask the resident wavefront to leave and wait until it has (it also leaves by itself when idle).
+static void session_park(gmr_session *s) {
+  if (!s->box || !s->st) return;
+  __atomic_store_n(&s->box->stop, 1u, __ATOMIC_RELEASE);
+  (void)hipStreamSynchronize(s->st);
+  __atomic_store_n(&s->box->stop, 0u, __ATOMIC_RELEASE);
+  __atomic_store_n(&s->box->exited_gen, s->gen, __ATOMIC_RELEASE);  // (what the wavefront wrote itself, unless it faulted)
 }
 
 void gmr_session_destroy(gmr_session *s) {
   if (!s) return;
   if (s->m && s->m->device >= 0) (void)hipSetDevice(s->m->device);
+  session_park(s);
   if (s->st) { (void)hipStreamSynchronize(s->st); (void)hipStreamDestroy(s->st); }
   if (s->host) (void)hipHostFree(s->host);
   if (s->dev) (void)hipFree(s->dev);
@@ -1143,9 +1182,61 @@ int gmr_session_reset(gmr_session *s, const double *qpos) {
   gmr_model *m = s->m;
   const double *src = qpos ? qpos : blob_ptr<double>(m->blob, m->h.off_qpos0);
   HIP_TRY(m, hipSetDevice(m->device));
+  session_park(s);
   HIP_TRY(m, hipStreamSynchronize(s->st));
   HIP_TRY(m, hipMemcpy(s->dev, src, sizeof(double) * (size_t)m->h.nq, hipMemcpyHostToDevice));
   return GMR_OK;
+}
+
+int gmr_session_set_persistent(gmr_session *s, int idle_ms) {
+  if (!s || idle_ms < 0 || idle_ms > 10000) return GMR_EINVAL;
+  gmr_model *m = s->m;
+  HIP_TRY(m, hipSetDevice(m->device));
+  session_park(s);
+  s->idle_ms = idle_ms;
+  return GMR_OK;
+}
+
+// One frame through the resident wavefront.  (Re)launches it when none is alive: the first frame, or after it left for idleness.
+static int session_step_persistent(gmr_session *s, int offset_to_ground) {
+  gmr_model *m = s->m;
+  gmr::IkSessionBox *box = s->box;
+  auto alive = [&]() { return __atomic_load_n(&box->exited_gen, __ATOMIC_ACQUIRE) != s->gen; };
+  auto launch = [&]() -> int {
+    const unsigned gen = ++s->gen;
+    const unsigned long long ticks = 100000ull * (unsigned long long)s->idle_ms;  // s_memrealtime: 100 MHz
+    const unsigned max_polls = (unsigned)std::min<unsigned long long>(4000ull * (unsigned long long)s->idle_ms, 0x7fffffffull);
+    switch (m->nvp) {
+#define GMR_X(v) case v: launch_ik_session<v>(m, s->entries, s->box_dev, ticks, max_polls, 1u << 20, gen, s->st); break;
+      GMR_FOR_EACH_NVP(GMR_X)
+#undef GMR_X
+      default: set_err(m, "internal: no kernel variant for nvp=%d", m->nvp); return GMR_EUNSUPPORTED;
+    }
+    HIP_TRY(m, hipGetLastError());
+    return GMR_OK;
+  };
+  const unsigned seq = (++s->seq << 1) | (offset_to_ground ? 1u : 0u);  // never equal to the previous word: the frame counter moved
+  __atomic_store_n(&box->seq, seq, __ATOMIC_RELEASE);
+  if (!alive()) {
+    int rc = launch();
+    if (rc != GMR_OK) return rc;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; ++spins) {
+    if (__atomic_load_n(&box->ack, __ATOMIC_ACQUIRE) == seq) return GMR_OK;
+    if (!alive() && __atomic_load_n(&box->ack, __ATOMIC_ACQUIRE) != seq) {
+      int rc = launch();  // it left between our post and its last look at the mailbox
+      if (rc != GMR_OK) return rc;
+    }
+    if ((spins & 1023u) == 1023u) {
+      if (hipStreamQuery(s->st) != hipErrorNotReady && __atomic_load_n(&box->ack, __ATOMIC_ACQUIRE) != seq && alive()) {  // the kernel is gone without saying so: a fault
+        set_err(m, "persistent session kernel ended unexpectedly: %s", hipGetErrorString(hipGetLastError()));
+        __atomic_store_n(&box->exited_gen, s->gen, __ATOMIC_RELEASE);
+        return GMR_EDEVICE;
+      }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) { set_err(m, "persistent session: no answer within 10 s"); return GMR_EDEVICE; }
+    }
+  }
 }
 
 int gmr_session_step(gmr_session *s, const void *human_pos, const void *human_quat, int offset_to_ground, double *qpos_out,
@@ -1156,12 +1247,17 @@ int gmr_session_step(gmr_session *s, const void *human_pos, const void *human_qu
   if (!human_pos || !human_quat || !qpos_out) { set_err(m, "null argument"); return GMR_EINVAL; }
   memcpy(s->host, human_pos, s->pos_bytes);
   memcpy(s->host + s->quat_off, human_quat, s->quat_bytes);
-  gmr::IkLaunch L = s->L;
-  L.prm.offset_to_ground = offset_to_ground ? 1 : 0;
   HIP_TRY(m, hipSetDevice(m->device));
-  int rc = launch_ik_variant(m, L, s->st);
-  if (rc != GMR_OK) return rc;
-  HIP_TRY(m, hipStreamSynchronize(s->st));
+  if (s->idle_ms > 0) {
+    int rc = session_step_persistent(s, offset_to_ground);
+    if (rc != GMR_OK) return rc;
+  } else {
+    gmr::IkLaunch L = s->L;
+    L.prm.offset_to_ground = offset_to_ground ? 1 : 0;
+    int rc = launch_ik_variant(m, L, s->st);
+    if (rc != GMR_OK) return rc;
+    HIP_TRY(m, hipStreamSynchronize(s->st));
+  }
   const size_t nq = (size_t)m->h.nq;
   memcpy(qpos_out, s->host + s->out_off, nq * 8);
   if (solves_out) memcpy(solves_out, s->host + s->out_off + nq * 8, sizeof(int32_t));
@@ -1172,6 +1268,7 @@ int gmr_session_state(gmr_session *s, double *qpos_out) {
   if (!s || !qpos_out) return GMR_EINVAL;
   gmr_model *m = s->m;
   HIP_TRY(m, hipSetDevice(m->device));
+  session_park(s);
   HIP_TRY(m, hipStreamSynchronize(s->st));
   HIP_TRY(m, hipMemcpy(qpos_out, s->dev, sizeof(double) * (size_t)m->h.nq, hipMemcpyDeviceToHost));
   return GMR_OK;

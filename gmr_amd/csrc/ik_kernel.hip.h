@@ -1126,8 +1126,29 @@ __device__ __forceinline__ IkLaunchK *ik_args(IkLaunchK *p) {
 }
 
 // ------------------------------------------------------------------ the kernel body: one work item on one wavefront
-template <int NVP, bool SQ>
-__device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLayout lay, const int item) {
+// A live session as ONE resident wavefront (SURVEY f-4: "a persistent-kernel single-sequence mode"): instead of a launch and a
+// stream synchronisation per frame, the host posts frames in a pinned mailbox and the wavefront -- ik_body<.., LIVE = true>,
+// whose frame loop then waits for the mailbox instead of walking an array -- solves them as they arrive, its tree, plans and
+// configuration staying in LDS / registers between frames.
+//   host:   inputs -> pinned buffer, then box.seq = 2 n + offset_to_ground (release)                   ... spins on box.ack == seq
+//   device: spins on box.seq != last (acquire, system scope: also drops stale L1 lines), solves the frame in the pinned buffer,
+//           results -> pinned buffer, box.ack = n (release)
+// Every wait is bounded: the wavefront leaves -- storing its state for the next one and writing its generation to box.exited_gen,
+// so that the host launches a fresh one with its next frame (launches are numbered; "alive" = the latest generation has not
+// reported leaving) -- after idle_ticks of the 100 MHz constant clock without a frame, after max_polls polls (a second bound
+// that needs no clock), after max_frames frames, or when the host raises box.stop.
+struct IkSessionBox {
+  unsigned seq, pad3, stop, pad0;           // written by the host
+  unsigned ack, exited_gen, pad1, pad2;     // written by the device: last frame answered; generation of the last wavefront that left
+};
+struct IkLive {
+  IkSessionBox *box;
+  unsigned long long idle_ticks;
+  unsigned max_polls, max_frames;
+};
+
+template <int NVP, bool SQ, bool LIVE = false>
+__device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLayout lay, const int item, const IkLive live = IkLive{}) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
   double *q = lds + lay.q, *xpos = lds + lay.xpos, *xquat = lds + lay.xquat, *tp = lds + lay.tp, *tq = lds + lay.tq;
@@ -1192,7 +1213,10 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
   __syncthreads();
   const double hscale = w.height_scale != 0.0 ? w.height_scale : 1.0;  // per-clip human height factor (gmr_blob.h)
 
-  const int nfr = w.n_burn + w.n_out;
+  const int nfr = LIVE ? (int)live.max_frames : w.n_burn + w.n_out;
+  unsigned live_last = 0, live_seq = 0;
+  bool live_otg = false;
+  if constexpr (LIVE) live_last = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&live.box->ack, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
   bool poses_valid = false;
   // Verification walk (check_stride > 0, gmr_blob.h): the item runs down a clip whose chunks were already solved
   // speculatively.  At every chunk boundary the state is compared with the state B that chunk started its output from: equal
@@ -1200,6 +1224,20 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
   // different -> solve the chunk here, from the true state.  kc = chunk index, left = frames left in the chunk being solved.
   int out_done = 0, kc = 0, left = 0;
   for (int kf = 0; kf < nfr; ++kf) {
+    if constexpr (LIVE) {  // wait for the host's next frame (every value made wave-uniform: the loop must not diverge)
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      unsigned polls = 0;
+      bool leave = false;
+      for (;;) {
+        live_seq = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&live.box->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM));
+        if (live_seq != live_last) break;
+        const int stop = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&live.box->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        if (stop != 0 || ++polls >= live.max_polls || __builtin_amdgcn_s_memrealtime() - t0 > live.idle_ticks) { leave = true; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (leave) break;
+      live_otg = (live_seq & 1u) != 0;  // bit 0 of the posted word: this frame's offset_to_ground (one PCIe read less than a second field)
+    }
     if (w.check_stride > 0 && left == 0) {
       double *B = ik_args(Lk)->qfinal + (size_t)(w.burn_row + kc) * nq;
       double d = 0.0;
@@ -1218,7 +1256,7 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
       for (int i = lane; i < nq; i += 64) B[i] = q[i];  // this chunk now starts from the state found here
       left = len;
     }
-    const int64_t f = w.frame_begin + kf;
+    const int64_t f = LIVE ? (int64_t)0 : w.frame_begin + kf;  // a live frame always sits in row 0 of the pinned buffers
     if (w.check_stride == 0 && kf == w.n_burn && w.burn_row >= 0) {  // state the first output frame starts from
       double *qfin = ik_args(Lk)->qfinal;
       if (qfin)
@@ -1269,7 +1307,7 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
         for (int i = 0; i < 3; i++) p[i] += g[i];
         if (m.sfoot[lane]) pz = p[2];
       }
-      if (La->prm.offset_to_ground) {
+      if (LIVE ? live_otg : La->prm.offset_to_ground != 0) {
         const double lowest = wave_min(pz);
         p[2] = p[2] - lowest + 0.1;
       }
@@ -1626,6 +1664,11 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
       }
     }
     __syncthreads();
+    if constexpr (LIVE) {  // the result stores of every lane are issued (barrier above): order them before the acknowledgement
+      __threadfence_system();
+      if (lane == 0) __hip_atomic_store(&live.box->ack, live_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      live_last = live_seq;
+    }
   }
   {
     IkLaunchK *Le = ik_args(Lk);
@@ -1674,6 +1717,25 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_group_kernel(con
   GMR_LAY(xpos) GMR_LAY(xquat) GMR_LAY(B) GMR_LAY(Bc) GMR_LAY(H) GMR_LAY(total_doubles)
 #undef GMR_LAY
   ik_body<NVP, SQ>(*(DevModelG *)E->m, &E->L, lay, (int)blockIdx.x - E->item_base);
+#endif
+}
+
+// The resident wavefront of a persistent session (see IkSessionBox above): entries[0] is the session's one-frame work item.
+template <int NVP, bool SQ>
+__global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_session_kernel(const IkGroupEntry *__restrict__ entries, IkSessionBox *box,
+                                                                               unsigned long long idle_ticks, unsigned max_polls,
+                                                                               unsigned max_frames, unsigned gen) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const auto *E = (const IkGroupEntry __attribute__((address_space(4))) *)(uintptr_t)entries;
+  LdsLayout lay;
+#define GMR_LAY(f) lay.f = E->lay.f;
+  GMR_LAY(zero) GMR_LAY(hplan) GMR_LAY(cplan) GMR_LAY(q) GMR_LAY(tp) GMR_LAY(tq) GMR_LAY(S) GMR_LAY(F) GMR_LAY(Lb) GMR_LAY(bodyc)
+  GMR_LAY(xpos) GMR_LAY(xquat) GMR_LAY(B) GMR_LAY(Bc) GMR_LAY(H) GMR_LAY(total_doubles)
+#undef GMR_LAY
+  ik_body<NVP, SQ, true>(*(DevModelG *)E->m, &E->L, lay, 0, IkLive{box, idle_ticks, max_polls, max_frames});
+  __syncthreads();
+  __threadfence_system();
+  if (threadIdx.x == 0) __hip_atomic_store(&box->exited_gen, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 #endif
 }
 

@@ -155,6 +155,12 @@ int gmr_session_reset(gmr_session *s, const double *qpos);
 int gmr_session_step(gmr_session *s, const void *human_pos, const void *human_quat, int offset_to_ground, double *qpos_out,
                      int32_t *solves_out);
 int gmr_session_state(gmr_session *s, double *qpos_out);
+/* Persistent mode (idle_ms > 0): frames are handed to ONE resident wavefront through a pinned mailbox instead of a launch and a
+ * stream synchronisation each -- the latency of a step drops from ~49 us to the wavefront's own solve time plus two PCIe hops.
+ * The wavefront leaves by itself after idle_ms without a frame (and is relaunched by the next step), on reset / state / destroy,
+ * and every wait inside it is bounded.  While it is resident, device-wide synchronisation (hipDeviceSynchronize, hipFree) waits
+ * for it to idle out, which is why the mode is opt-in.  idle_ms = 0 returns to one launch per frame.  Results are identical. */
+int gmr_session_set_persistent(gmr_session *s, int idle_ms);
 
 /* Evaluate, per frame, the stage errors |concat_t Log(T_body^-1 T_target)| of both tables and/or the MuJoCo-convention FK.
  *   qpos device [n][nq] f64;  human_pos/human_quat/in_dtype/n_cols/slot_col as in gmr_ik_solve (needed only with err_out)

@@ -755,3 +755,53 @@ def test_planar_base_robot_through_the_class():
     from gmr_amd import dataset
     with pytest.raises(NotImplementedError):
         dataset.retarget_clips(g, pos, quat, names, offs)
+
+
+def test_persistent_session_is_the_batch_solver_fed_frame_by_frame():
+    """gmr_session_set_persistent: frames through one resident wavefront and a pinned mailbox (SURVEY f-4).  The wavefront keeps its
+    state in LDS between frames exactly like a multi-frame work item, so the result equals the batched solve of the same frames
+    bit for bit (a launch per frame re-reads its state and differs in the last bit); it leaves when idle and the next frame brings
+    a new one; reset / state / offset_to_ground / mode switches / destroy work while it is resident."""
+    import time
+    from gmr_amd.engine import Engine, IKParams
+    cm = compiled("smplx", "unitree_g1")
+    eng = Engine(cm)
+    T = 80
+    pos, quat, names, offs, _ = synth.synth_clips(cm, 1, T, seed=23, hard=True, dtype=np.float32)
+    sc = cm.slot_columns(names)
+    dev = torch.device("cuda", 0)
+    q_batch, it_batch, _ = eng.ik_solve(torch.from_numpy(pos).to(dev), torch.from_numpy(quat).to(dev), sc, make_items(offs))
+    q_batch, it_batch = q_batch.cpu().numpy(), it_batch.cpu().numpy()
+    b = eng.session(sc, pos.shape[1], IKParams(), dtype=np.float32)
+    b.set_persistent(200)
+    lat = []
+    for f in range(T):
+        t0 = time.perf_counter()
+        qb, nb = b.step(pos[f], quat[f])
+        lat.append(time.perf_counter() - t0)
+        # bit for bit while one wavefront stays resident; a relaunch re-reads the state like a launch per frame does (last bit)
+        assert (np.array_equal(qb, q_batch[f]) if f <= 20 else np.abs(qb - q_batch[f]).max() < 1e-9) and nb == it_batch[f], f
+        if f == 20:  # the resident wavefront idles out (idle 20 ms) and the next frame brings a new one, continuing from its state
+            b.set_persistent(20)
+            time.sleep(0.08)
+        if f == 30:
+            assert np.array_equal(b.state(), qb)
+        if f == 45:
+            b.set_persistent(0)    # back to one launch per frame (last-bit differences from here on) ...
+        if f == 50:
+            b.set_persistent(200)  # ... and resident again
+            break
+    for f in range(51, T):
+        qb, nb = b.step(pos[f], quat[f])
+        assert np.abs(qb - q_batch[f]).max() < 1e-9 and nb == it_batch[f], f
+    print(f"persistent session step latency: median {1e6 * np.median(lat):.0f} us")
+    # offset_to_ground rides on the posted word; a launch-per-frame session is the comparison
+    a = eng.session(sc, pos.shape[1], IKParams(), dtype=np.float32)
+    a.reset(); b.reset()
+    for f in range(12):
+        qa, na = a.step(pos[f], quat[f], offset_to_ground=f % 3 == 1)
+        qb, nb = b.step(pos[f], quat[f], offset_to_ground=f % 3 == 1)
+        assert np.abs(qa - qb).max() < 1e-9 and na == nb, f
+    a.close()
+    b.close()  # destroyed while the wavefront is resident
+    torch.cuda.synchronize()

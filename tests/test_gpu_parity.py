@@ -119,6 +119,27 @@ def test_planar_base_robot_matches_oracle(hard, qp, dev, monkeypatch):
         assert np.all(q[:, 2] == cm.robot.body_pos[0, 2]) and not q[:, 4:6].any() and not q[:, 7:13].any()  # z, roll / pitch, wheels
 
 
+@pytest.mark.parametrize("prm", [dict(damping=0.05), dict(damping=4.0, max_iter=3), dict(tol=1e-5, max_iter=20), dict(limit_gain=0.5, lm_damping=0.1),
+                                 dict(max_iter=0)])
+def test_solver_constants_are_the_callers(prm, dev):
+    """gmr_ik_params: damping is a constructor argument of the reference class (motion_retarget.py:19), max_iter an attribute
+    callers set (:56); tol, limit_gain and lm_damping are the values the reference hard-codes.  Every one of them reaches the
+    kernel: non-default values against the oracle with the same values, on inputs that reach joint limits."""
+    from gmr_amd.engine import IKParams
+    cm = compiled("smplx", "unitree_g1")
+    eng, orc = _engine(cm), Oracle(cm.blob)
+    pos, quat, names, offs, _ = synth.synth_clips(cm, 3, 30, seed=17, hard=True, dtype=np.float32)
+    sc = cm.slot_columns(names)
+    q_ref, it_ref, _ = orc.ik_solve(pos, quat, sc, make_items(offs), params=OParams(**prm))
+    q, it, _ = eng.ik_solve(torch.from_numpy(pos).to(dev), torch.from_numpy(quat).to(dev), sc, make_items(offs), params=IKParams(**prm))
+    q, it = q.cpu().numpy(), it.cpu().numpy()
+    assert (it >> 30).max() == 0 and _qpos_diff(q, q_ref) < 1e-6 and np.array_equal(it, it_ref)
+    q_def, it_def, _ = orc.ik_solve(pos, quat, sc, make_items(offs))
+    assert _qpos_diff(q_ref, q_def) > 1e-4 or not np.array_equal(it_ref, it_def)  # the variation is not a no-op
+    if "max_iter" in prm:
+        assert it.max() <= 2 * (1 + prm["max_iter"])
+
+
 def _synthetic_robot(tmp_path, limbs, with_tasks_per_limb, jrange="-1.2 1.4", table2_reversed=False):
     """A floating base with `limbs` chains of hinges (list of chain lengths) hanging off it; tasks on the base and on every
     `with_tasks_per_limb`-th link of each chain.  Returns a compiled model."""
