@@ -1331,9 +1331,13 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
           if (cy >= 0.0) { ch = fast_sqrt(0.5 * (1.0 + cy)); sh = fast_div(0.5 * sy, ch); }
           else { sh = fast_sqrt(0.5 * (1.0 - cy)); sh = sy < 0.0 ? -sh : sh; ch = fast_div(0.5 * sy, sh); }
         }
-        if (lane < 2) q[lane] = tp[3 * rts + lane];
-        if (lane >= 3 && lane < 7) q[lane] = lane == 3 ? ch : lane == 6 ? sh : 0.0;
-      } else if (lane < 7) q[lane] = lane < 3 ? tp[3 * rts + lane] : tq[4 * rts + lane - 3];
+        const int ln = launder(lane);  // (cold path: keep its lane predicates out of the frame loop's hoisted masks)
+        if (ln < 2) q[ln] = tp[3 * rts + ln];
+        if (ln >= 3 && ln < 7) q[ln] = ln == 3 ? ch : ln == 6 ? sh : 0.0;
+      } else {
+        const int ln = launder(lane);
+        if (ln < 7) q[ln] = ln < 3 ? tp[3 * rts + ln] : tq[4 * rts + ln - 3];
+      }
       __syncthreads();
     }
     GMR_STAMP(0);
@@ -1631,6 +1635,16 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
         __syncthreads();
         GMR_STAMP(9);
         ++solves;
+#ifdef GMR_EXP_READLANE  // experiment: what N extra SGPR-spill-style reloads per solve cost (tools/build_variant.sh)
+        {
+          int vv = (int)lane;
+#pragma unroll
+          for (int r = 0; r < GMR_EXP_READLANE; r++) {
+            int ss;
+            asm volatile("v_readlane_b32 %0, %1, 5\n\ts_nop 0" : "=s"(ss) : "v"(vv));
+          }
+        }
+#endif
 #ifdef GMR_DUP_PHASE
         fk_phase<GMR_IK_STAGE_TREE != 0, true, true>(m, bodyc, nbody, fkrounds, lane, q, xpos, xquat, wx, wy, wz, &fkj);
         if (launder(GMR_DUP_PHASE == 1 ? 1 : 0)) fk_phase<GMR_IK_STAGE_TREE != 0>(m, bodyc, nbody, fkrounds, lane, q, xpos, xquat);
