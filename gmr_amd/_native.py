@@ -26,7 +26,7 @@ INIT_QPOS0, INIT_ROOT_TARGET = -1, -2
 
 EXPORTS = ["gmr_abi_version", "gmr_model_create", "gmr_model_destroy", "gmr_last_error", "gmr_model_info_get",
            "gmr_ik_solve", "gmr_fk", "gmr_fk_min_height", "gmr_bvh_fk", "gmr_bvh_parse_header", "gmr_bvh_parse_motion", "gmr_evaluate", "gmr_smplx_keypoints",
-           "gmr_session_create", "gmr_session_destroy", "gmr_session_reset", "gmr_session_step", "gmr_session_state", "gmr_session_set_persistent",
+           "gmr_session_create", "gmr_session_destroy", "gmr_session_reset", "gmr_session_step", "gmr_session_state", "gmr_session_set_persistent", "gmr_ik_plan_order", "gmr_ik_solve_ordered",
            "gmr_group_create", "gmr_group_destroy", "gmr_group_size", "gmr_group_model", "gmr_group_last_error", "gmr_group_ik_solve"]
 
 
@@ -112,6 +112,11 @@ def load():
     L.gmr_group_last_error.restype = C.c_char_p
     L.gmr_group_last_error.argtypes = [vp]
     L.gmr_group_ik_solve.restype = C.c_int
+    L.gmr_ik_plan_order.restype = C.c_int
+    L.gmr_ik_plan_order.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int64, vp, C.c_int, C.POINTER(IKParams), vp, C.c_int, vp, vp]
+    L.gmr_ik_solve_ordered.restype = C.c_int
+    L.gmr_ik_solve_ordered.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int64, vp, C.c_int, C.POINTER(IKParams), vp, vp, vp, vp, vp,
+                                       C.POINTER(IKStats), vp, vp]
     L.gmr_group_ik_solve.argtypes = [vp, C.POINTER(GroupInput), C.POINTER(IKParams), vp]
     L.gmr_bvh_parse_header.restype = C.c_int
     L.gmr_bvh_parse_header.argtypes = [C.c_char_p, C.c_size_t, C.c_int, vp, C.c_size_t, vp, vp, vp, vp, vp, vp, vp]

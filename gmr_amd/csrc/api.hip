@@ -145,8 +145,16 @@ int pick_nvp(int n_act) {
 }
 
 template <int NVP>
-void launch_ik(const gmr_model *m, const gmr::IkLaunch &L, hipStream_t st) {
-  if (m->dm.sq_ok && !m->force_generic)
+void launch_ik(const gmr_model *m, const gmr::IkLaunch &L, hipStream_t st, bool probe) {
+  const bool sq = m->dm.sq_ok && !m->force_generic;
+  if (probe) {
+    if (sq) hipLaunchKernelGGL((gmr::ik_probe_kernel<NVP, true>), dim3(L.n_items), dim3(64), m->lds_bytes, st, m->dm_dev, L, m->lay);
+#ifndef GMR_IK_DEV_ONLY36
+    else hipLaunchKernelGGL((gmr::ik_probe_kernel<NVP, false>), dim3(L.n_items), dim3(64), m->lds_bytes, st, m->dm_dev, L, m->lay);
+#endif
+    return;
+  }
+  if (sq)
     hipLaunchKernelGGL((gmr::ik_kernel<NVP, true>), dim3(L.n_items), dim3(64), m->lds_bytes, st, m->dm_dev, L, m->lay);
 #ifndef GMR_IK_DEV_ONLY36
   else
@@ -154,9 +162,9 @@ void launch_ik(const gmr_model *m, const gmr::IkLaunch &L, hipStream_t st) {
 #endif
 }
 
-int launch_ik_variant(gmr_model *m, const gmr::IkLaunch &L, hipStream_t st) {
+int launch_ik_variant(gmr_model *m, const gmr::IkLaunch &L, hipStream_t st, bool probe = false) {
   switch (m->nvp) {
-#define GMR_X(v) case v: launch_ik<v>(m, L, st); break;
+#define GMR_X(v) case v: launch_ik<v>(m, L, st, probe); break;
     GMR_FOR_EACH_NVP(GMR_X)
 #undef GMR_X
     default: set_err(m, "internal: no kernel variant for nvp=%d", m->nvp); return GMR_EUNSUPPORTED;
@@ -914,7 +922,8 @@ int gmr_model_info_get(const gmr_model *m, gmr_model_info *out) {
 static int prepare_ik_launch(gmr_model *m, const void *human_pos, const void *human_quat, int in_dtype, int n_cols, const int32_t *slot_col,
                              int64_t n_frames, const gmr_work_item *items, int n_items, const gmr_ik_params *params,
                              const double *qpos_init, double *qpos_final, double *qpos_out, int32_t *iters_out, int32_t *frames_done,
-                             gmr_ik_stats *stats, hipStream_t st, CallScratch &sc, gmr::IkLaunch &L, std::vector<gmr_work_item> &sorted) {
+                             gmr_ik_stats *stats, hipStream_t st, CallScratch &sc, gmr::IkLaunch &L, std::vector<gmr_work_item> &sorted,
+                             bool keep_order = false) {
   if (m->h.nslot == 0 || (m->h.ntask[0] == 0 && m->h.ntask[1] == 0)) { set_err(m, "model has no IK config"); return GMR_ENOCONFIG; }
   if (!human_pos || !human_quat || !slot_col || !params || !qpos_out || (!items && n_items > 0)) { set_err(m, "null argument"); return GMR_EINVAL; }
   if (in_dtype != GMR_DTYPE_F32 && in_dtype != GMR_DTYPE_F64) { set_err(m, "in_dtype must be f32 or f64"); return GMR_EINVAL; }
@@ -953,7 +962,8 @@ static int prepare_ik_launch(gmr_model *m, const void *human_pos, const void *hu
   // longest item first so that the tail of the grid is made of short ones
   std::vector<int> order(n_items);
   std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return items[a].n_burn + items[a].n_out > items[b].n_burn + items[b].n_out; });
+  if (!keep_order)  // (an ordered launch brings its own order: gmr_ik_solve_ordered)
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return items[a].n_burn + items[a].n_out > items[b].n_burn + items[b].n_out; });
   sorted.resize(n_items);
   for (int i = 0; i < n_items; ++i) sorted[i] = items[order[i]];
   const size_t items_bytes = sizeof(gmr_work_item) * (size_t)n_items, col_bytes = sizeof(int32_t) * (size_t)m->h.nslot;
@@ -991,6 +1001,69 @@ int gmr_ik_solve(gmr_model *m, const void *human_pos, const void *human_quat, in
   int rc = prepare_ik_launch(m, human_pos, human_quat, in_dtype, n_cols, slot_col, n_frames, items, n_items, params, qpos_init, qpos_final,
                              qpos_out, iters_out, frames_done, stats, st, sc, L, sorted);
   if (rc != GMR_OK || n_items == 0) return rc;
+  return launch_ik_variant(m, L, st);
+}
+
+// ---- launch order by predicted cost.  Items of equal length still differ in cost (solves per frame: 1.15 max / mean on the
+// bench mix), and with only a few items per wavefront slot the order they start in decides how long the last ones run alone:
+// 8192 x 3000 frames take 608 ms in array order and 549 ms most-expensive-first.  Lengths being equal, the only predictor is the
+// clip itself: gmr_ik_plan_order solves the first probe_frames of every item for their cost alone (nothing else is written)
+// and sorts on the device; gmr_ik_solve_ordered then runs the full items in that order.  Everything stays on the stream.
+int gmr_ik_plan_order(gmr_model *m, const void *human_pos, const void *human_quat, int in_dtype, int n_cols, const int32_t *slot_col,
+                      int64_t n_frames, const gmr_work_item *items, int n_items, const gmr_ik_params *params, const double *qpos_init,
+                      int probe_frames, int32_t *order_out, void *stream) {
+  if (!m) return GMR_EINVAL;
+  m->err.clear();
+  if (!order_out || probe_frames < 1) { set_err(m, "order_out is NULL or probe_frames < 1"); return GMR_EINVAL; }
+  if (n_items < 0 || (!items && n_items > 0)) { set_err(m, "null argument"); return GMR_EINVAL; }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  std::vector<gmr_work_item> probe(items, items + n_items);
+  std::vector<int> meta(3 * (size_t)std::max(n_items, 1));  // [cost | frames | probed]
+  for (int i = 0; i < n_items; ++i) {
+    gmr_work_item &w = probe[i];
+    if (w.check_stride != 0) { set_err(m, "work item %d: verification walks cannot be probed", i); return GMR_EINVAL; }
+    if (w.n_burn < 0 || w.n_out < 0) { set_err(m, "work item %d has a negative frame count", i); return GMR_EINVAL; }
+    const int total = w.n_burn + w.n_out, p = std::min(total, probe_frames);
+    meta[n_items + i] = total; meta[2 * n_items + i] = p;
+    w.n_burn = p; w.n_out = 0; w.final_row = -1; w.burn_row = -1;  // frames solved, nothing written
+  }
+  if (n_items == 0) return GMR_OK;
+  HIP_TRY(m, hipSetDevice(m->device));
+  CallScratch sc, ms;
+  gmr::IkLaunch L{};
+  std::vector<gmr_work_item> sorted;
+  double dummy_out = 0.0;  // (prepare_ik_launch insists on an output array; a probe item has no output frame to write)
+  int rc = prepare_ik_launch(m, human_pos, human_quat, in_dtype, n_cols, slot_col, n_frames, probe.data(), n_items, params, qpos_init, nullptr,
+                             &dummy_out, nullptr, nullptr, nullptr, st, sc, L, sorted);
+  if (rc != GMR_OK) return rc;
+  rc = scratch_alloc(m, ms, sizeof(int) * meta.size(), st);
+  if (rc != GMR_OK) return rc;
+  int *meta_dev = static_cast<int *>(ms.p);
+  HIP_TRY(m, hipMemcpyAsync(meta_dev, meta.data(), sizeof(int) * meta.size(), hipMemcpyHostToDevice, st));
+  L.qout = nullptr;
+  L.cost = meta_dev;
+  rc = launch_ik_variant(m, L, st, /*probe=*/true);
+  if (rc != GMR_OK) return rc;
+  hipLaunchKernelGGL(gmr::plan_order_kernel, dim3(1), dim3(1024), 0, st, meta_dev, meta_dev + n_items, meta_dev + 2 * n_items, n_items, order_out);
+  HIP_TRY(m, hipGetLastError());
+  return GMR_OK;
+}
+
+int gmr_ik_solve_ordered(gmr_model *m, const void *human_pos, const void *human_quat, int in_dtype, int n_cols, const int32_t *slot_col,
+                         int64_t n_frames, const gmr_work_item *items, int n_items, const gmr_ik_params *params, const double *qpos_init,
+                         double *qpos_final, double *qpos_out, int32_t *iters_out, int32_t *frames_done, gmr_ik_stats *stats,
+                         const int32_t *launch_order, void *stream) {
+  if (!m) return GMR_EINVAL;
+  m->err.clear();
+  if (!launch_order && n_items > 0) { set_err(m, "launch_order is NULL"); return GMR_EINVAL; }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  CallScratch sc;
+  gmr::IkLaunch L{};
+  std::vector<gmr_work_item> sorted;
+  int rc = prepare_ik_launch(m, human_pos, human_quat, in_dtype, n_cols, slot_col, n_frames, items, n_items, params, qpos_init, qpos_final,
+                             qpos_out, iters_out, frames_done, stats, st, sc, L, sorted, /*keep_order=*/true);
+  if (rc != GMR_OK || n_items == 0) return rc;
+  L.perm = launch_order;
   return launch_ik_variant(m, L, st);
 }
 

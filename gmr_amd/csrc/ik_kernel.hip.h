@@ -154,6 +154,8 @@ struct IkLaunch {
   int in_f64, n_cols, n_items, pad;
   gmr_ik_params prm;
   u64 *dbg;  // [16] phase cycle sums, diagnostic builds only
+  const int *perm;  // [n_items] or NULL: workgroup b runs item perm[b] (a launch order made on the device, gmr_ik_plan_order)
+  int *cost;        // ik_probe_kernel only: [n_items] solves spent on each item, indexed like frames_done
 };
 
 // Opaque to the optimiser: values derived from it cannot be hoisted out of the enclosing loop.  Used on indices of
@@ -1147,7 +1149,7 @@ struct IkLive {
   unsigned max_polls, max_frames;
 };
 
-template <int NVP, bool SQ, bool LIVE = false>
+template <int NVP, bool SQ, bool LIVE = false, bool PROBE = false>
 __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLayout lay, const int item, const IkLive live = IkLive{}) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
@@ -1223,6 +1225,7 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
   // -> the chunk's stored frames are what a sequential run would produce, adopt its stored final state F and skip it;
   // different -> solve the chunk here, from the true state.  kc = chunk index, left = frames left in the chunk being solved.
   int out_done = 0, kc = 0, left = 0;
+  int cost_acc = 0;  // PROBE: solves spent on this item
   for (int kf = 0; kf < nfr; ++kf) {
     if constexpr (LIVE) {  // wait for the host's next frame (every value made wave-uniform: the loop must not diverge)
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -1664,6 +1667,7 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
         curr = next;
       }
     }
+    if constexpr (PROBE) cost_acc += solves;
     if (kf >= w.n_burn) {
       IkLaunchK *Lo = ik_args(Lk);
       double *qout = Lo->qout;
@@ -1687,7 +1691,11 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
   {
     IkLaunchK *Le = ik_args(Lk);
     int *fdone = Le->frames_done;
-    if (fdone && lane == 0) fdone[Le->order[item]] = out_done;
+    if (fdone && lane == 0) fdone[Le->order ? Le->order[item] : item] = out_done;
+    if constexpr (PROBE) {
+      int *cost = Le->cost;
+      if (cost && lane == 0) cost[Le->order ? Le->order[item] : item] = cost_acc;
+    }
     double *qfin = Le->qfinal;
     if (w.check_stride == 0 && w.final_row >= 0 && qfin)
       for (int i = lane; i < nq; i += 64) qfin[(size_t)w.final_row * nq + i] = q[i];
@@ -1703,7 +1711,44 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
 template <int NVP, bool SQ>
 __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const DevModel *__restrict__ mp, IkLaunch L, LdsLayout lay) {
   IkLaunchK *Lk = (IkLaunchK *)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + 8);
-  ik_body<NVP, SQ>(*(DevModelG *)mp, Lk, lay, (int)blockIdx.x);
+  const int *perm = Lk->perm;  // a device-made launch order (gmr_ik_solve_ordered), else items run in array order
+  ik_body<NVP, SQ>(*(DevModelG *)mp, Lk, lay, perm ? __builtin_amdgcn_readfirstlane(perm[blockIdx.x]) : (int)blockIdx.x);
+}
+
+// The probe in front of an ordered launch (gmr_ik_plan_order): the first frames of every item, solved for their cost only --
+// nothing is written but cost[item], the number of solves they took.
+template <int NVP, bool SQ>
+__global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_probe_kernel(const DevModel *__restrict__ mp, IkLaunch L, LdsLayout lay) {
+  IkLaunchK *Lk = (IkLaunchK *)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + 8);
+  ik_body<NVP, SQ, false, true>(*(DevModelG *)mp, Lk, lay, (int)blockIdx.x);
+}
+
+// Launch order from the probe: items by predicted cost (probe solves per frame x frames), most expensive first.  One workgroup;
+// a counting sort over 4096 cost buckets -- the order inside a bucket is whatever the atomics make it, which is all a
+// longest-expected-first launch needs.  frames[i] / probed[i]: frames of item i in total / in the probe.
+__global__ void __launch_bounds__(1024) plan_order_kernel(const int *__restrict__ cost, const int *__restrict__ frames, const int *__restrict__ probed,
+                                                          int n, int *__restrict__ order_out) {
+  __shared__ unsigned hist[4096];
+  __shared__ float smax;
+  const int t = threadIdx.x;
+  auto key = [&](int i) { return probed[i] > 0 ? (float)cost[i] * (float)frames[i] / (float)probed[i] : 0.0f; };
+  float mx = 0.0f;
+  for (int i = t; i < n; i += 1024) mx = fmaxf(mx, key(i));
+  for (int i = t; i < 4096; i += 1024) hist[i] = 0u;
+  if (t == 0) smax = 0.0f;
+  __syncthreads();
+  atomicMax(reinterpret_cast<unsigned *>(&smax), __float_as_uint(mx));  // keys are non-negative: their bit patterns order like the values
+  __syncthreads();
+  const float scale = smax > 0.0f ? 4095.0f / smax : 0.0f;
+  auto bucket = [&](int i) { return 4095 - min(4095, (int)(key(i) * scale)); };  // bucket 0 = the most expensive
+  for (int i = t; i < n; i += 1024) atomicAdd(&hist[bucket(i)], 1u);
+  __syncthreads();
+  if (t == 0) {  // exclusive scan (4096 entries: not worth a parallel scan next to the launches it orders)
+    unsigned acc = 0;
+    for (int b = 0; b < 4096; ++b) { const unsigned c = hist[b]; hist[b] = acc; acc += c; }
+  }
+  __syncthreads();
+  for (int i = t; i < n; i += 1024) order_out[atomicAdd(&hist[bucket(i)], 1u)] = i;
 }
 
 // Several models in ONE launch (BASELINE config 4: heterogeneous trees): every workgroup looks up the entry its work item belongs

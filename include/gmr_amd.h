@@ -111,6 +111,22 @@ int gmr_ik_solve(gmr_model *m, const void *human_pos, const void *human_quat, in
                  const gmr_ik_params *params, const double *qpos_init, double *qpos_final, double *qpos_out,
                  int32_t *iters_out, int32_t *frames_done, gmr_ik_stats *stats, void *stream);
 
+/* Launch order by predicted cost.  Work items start in array order (gmr_ik_solve puts longer items first); items of EQUAL
+ * length still differ in cost -- solves per frame -- and with a few items per wavefront slot the start order decides how long the
+ * last ones run alone (8192 clips x 3000 frames: 608 ms in array order, 549 ms most-expensive-first).
+ *   gmr_ik_plan_order     solves the first probe_frames frames of every item for their cost only (nothing but order_out is
+ *                         written) and orders the items by probe solves per frame x frames, most expensive first.
+ *                         order_out device int32 [n_items]; other arguments as gmr_ik_solve; plain items only (no check_stride)
+ *   gmr_ik_solve_ordered  gmr_ik_solve with workgroup b running item launch_order[b] (device int32 [n_items], a permutation)
+ * Both are asynchronous on `stream`; results are those of gmr_ik_solve bit for bit (the order only moves work in time).        */
+int gmr_ik_plan_order(gmr_model *m, const void *human_pos, const void *human_quat, int in_dtype, int n_cols, const int32_t *slot_col,
+                      int64_t n_frames, const gmr_work_item *items, int n_items, const gmr_ik_params *params, const double *qpos_init,
+                      int probe_frames, int32_t *order_out, void *stream);
+int gmr_ik_solve_ordered(gmr_model *m, const void *human_pos, const void *human_quat, int in_dtype, int n_cols, const int32_t *slot_col,
+                         int64_t n_frames, const gmr_work_item *items, int n_items, const gmr_ik_params *params, const double *qpos_init,
+                         double *qpos_final, double *qpos_out, int32_t *iters_out, int32_t *frames_done, gmr_ik_stats *stats,
+                         const int32_t *launch_order, void *stream);
+
 /* Several models in ONE launch (BASELINE config 4, "heterogeneous trees in one launch"): a group owns n models built for one
  * common kernel variant; gmr_group_ik_solve runs every member's work items in a single grid -- each wavefront looks up its
  * member's model, LDS layout and input / output arrays.  The reference analogue is one GeneralMotionRetargeting per robot in

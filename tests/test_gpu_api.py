@@ -805,3 +805,48 @@ def test_persistent_session_is_the_batch_solver_fed_frame_by_frame():
     a.close()
     b.close()  # destroyed while the wavefront is resident
     torch.cuda.synchronize()
+
+
+def test_launch_order_by_probe_moves_work_in_time_only():
+    """gmr_ik_plan_order / gmr_ik_solve_ordered: the probe's order is a permutation that ranks the expensive clips first, the ordered
+    launch gives bit for bit what the plain launch gives (qpos, solve counts, frames_done), and `launch_order="auto"` plans only
+    when there are more equal-length items than wavefront slots."""
+    from gmr_amd.engine import Engine, EngineError
+    cm = compiled("smplx", "unitree_g1")
+    eng = Engine(cm)
+    dev = torch.device("cuda", 0)
+    T, D = 96, 16
+    pe, qe, names, _, _ = synth.synth_clips(cm, D // 2, T, seed=31, hard=False, dtype=np.float32)
+    ph, qh, _, _, _ = synth.synth_clips(cm, D // 2, T, seed=32, hard=True, dtype=np.float32)
+    S = 2304  # > 8 x 256 wavefront slots
+    pos = torch.from_numpy(np.concatenate([pe, ph])).to(dev).repeat(S // D, 1, 1).contiguous()
+    quat = torch.from_numpy(np.concatenate([qe, qh])).to(dev).repeat(S // D, 1, 1).contiguous()
+    offs = np.arange(S + 1, dtype=np.int64) * T
+    items = make_items(offs)
+    sc = cm.slot_columns(names)
+    fd0 = torch.zeros(S, dtype=torch.int32, device=dev)
+    q0, it0, _ = eng.ik_solve(pos, quat, sc, items, launch_order=None, frames_done=fd0)
+    order = eng.plan_order(pos, quat, sc, items, probe_frames=24)
+    o = order.cpu().numpy()
+    assert sorted(o.tolist()) == list(range(S))
+    work = (it0.reshape(S, T).to(torch.int64) & 0x3FFFFFFF).sum(1).cpu().numpy()
+    first, last = work[o[: S // 4]].mean(), work[o[-S // 4:]].mean()
+    assert first > 1.08 * last, (first, last)          # the expensive quarter leads
+    fd1 = torch.zeros(S, dtype=torch.int32, device=dev)
+    q1, it1, _ = eng.ik_solve(pos, quat, sc, items, launch_order=order, frames_done=fd1)
+    assert torch.equal(q0, q1) and torch.equal(it0, it1) and torch.equal(fd0, fd1) and int(fd1.min()) == T
+    # "auto": equal lengths and more items than slots -> planned (same result); PROBE_MIN_LENGTH keeps short items out
+    assert not eng._order_pays(items) and eng._order_pays(make_items(np.arange(S + 1, dtype=np.int64) * 600))
+    assert not eng._order_pays(make_items(offs[:1025])) and not eng._order_pays(make_items(np.cumsum(np.r_[0, np.tile([600, 900], S // 2)])))
+    eng.PROBE_MIN_LENGTH = 64
+    try:
+        assert eng._order_pays(items)
+        q2, it2, _ = eng.ik_solve(pos, quat, sc, items)  # launch_order="auto"
+        assert torch.equal(q0, q2) and torch.equal(it0, it2)
+    finally:
+        del eng.PROBE_MIN_LENGTH
+    with pytest.raises(EngineError):
+        eng.ik_solve(pos, quat, sc, items, launch_order=order[:-1].contiguous())
+    walk = items.copy(); walk["check_stride"][0] = 4
+    with pytest.raises(EngineError):
+        eng.plan_order(pos, quat, sc, walk)
