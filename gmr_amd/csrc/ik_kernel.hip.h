@@ -1672,8 +1672,12 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
       IkLaunchK *Lo = ik_args(Lk);
       double *qout = Lo->qout;
       int *itp = Lo->iters;
-      for (int i = lane; i < nq; i += 64) qout[(size_t)f * nq + i] = q[i];
-      if (itp && lane == 0) itp[f] = solves | (qpflag << 30);
+      bool bad = false;  // a non-finite coordinate (x - x is 0 exactly for every finite x): reported in bit 31 of the frame's count
+      for (int i = lane; i < nq; i += 64) { const double v = q[i]; qout[(size_t)f * nq + i] = v; bad |= !(v - v == 0.0); }
+      if (itp) {  // (wave-uniform)
+        const int nonfinite = __builtin_amdgcn_ballot_w64(bad) != 0ull;
+        if (lane == 0) itp[f] = solves | (qpflag << 30) | (nonfinite << 31);
+      }
       ++out_done;
       if (w.check_stride > 0 && --left == 0) {  // a chunk solved here: its final state
         double *Fk = ik_args(Lk)->qfinal + (size_t)(w.final_row + kc) * nq;

@@ -74,7 +74,8 @@ class Engine:
     def ik_solve(self, pos: torch.Tensor, quat: torch.Tensor, slot_col: np.ndarray, items: np.ndarray,
                  params: Optional[IKParams] = None, qpos_init: Optional[torch.Tensor] = None, n_final: int = 0,
                  want_iters: bool = True, out: Optional[torch.Tensor] = None, qpos_final: Optional[torch.Tensor] = None,
-                 iters: Optional[torch.Tensor] = None, frames_done: Optional[torch.Tensor] = None, launch_order="auto"):
+                 iters: Optional[torch.Tensor] = None, frames_done: Optional[torch.Tensor] = None, launch_order="auto",
+                 _host_out: bool = False):
         """pos [N,B,3], quat [N,B,4] (float32 or float64 CUDA tensors) -> qpos [N,nq] float64.
 
         Frames not covered by any item's output range are left as NaN.  Returns (qpos, iters or None, qpos_final or None).
@@ -98,7 +99,8 @@ class Engine:
         prm = params or IKParams()
         if out is None:
             out = torch.full((N, self.nq), float("nan"), dtype=torch.float64, device=self.device)
-        elif out.shape != (N, self.nq) or out.dtype != torch.float64 or not out.is_contiguous() or out.device != self.device:
+        elif out.shape != (N, self.nq) or out.dtype != torch.float64 or not out.is_contiguous() or \
+                (out.device != self.device and not (_host_out and out.is_pinned())):
             raise EngineError("out must be a contiguous float64 [N, nq] tensor on the engine's device")
         if iters is None:
             iters = torch.zeros(N, dtype=torch.int32, device=self.device) if want_iters else None
@@ -184,22 +186,25 @@ class Engine:
         return order
 
     def ik_solve_host(self, pos: np.ndarray, quat: np.ndarray, slot_col: np.ndarray, seq_offsets, params: Optional[IKParams] = None,
-                      height_scales=None, min_batch_clips: int = 2048, max_batches: int = 4, want_iters: bool = True, check: bool = True,
-                      out: Optional[np.ndarray] = None):
+                      height_scales=None, first_batch_clips: Optional[int] = None, max_batch_frames: int = 1 << 25, want_iters: bool = True,
+                      check: bool = True, out: Optional[np.ndarray] = None):
         """Whole clips from HOST arrays to a HOST result, pipelined: what the dataset scripts hand over
         (scripts/smplx_to_robot_dataset.py:84-89 builds host key-points per file) without a serial copy-in / solve / copy-out.
 
-        Clips are grouped into up to ``max_batches`` batches of at least ``min_batch_clips`` clips (one wavefront per clip:
-        a batch should fill the chip's 2048 wavefront slots).  Batches alternate between two HIP streams, each with its own
-        device buffers: batch k+1's key-points cross PCIe (the caller's pageable arrays are read in place -- all their columns;
-        ``slot_col`` picks the ones the config consumes on the device) while batch k's kernel runs, and every batch's qpos goes
-        straight into a pinned host result (a fresh pageable result array would cost more in page faults than the kernel takes).
+        * in: the caller's pageable arrays are read in place by the copy engine (all their columns; ``slot_col`` picks the ones the
+          config consumes on the device), batch by batch, into two alternating device buffers on two HIP streams, so that batch
+          k+1 crosses PCIe while batch k's kernel runs.  The first batch is small -- ``first_batch_clips``, by default one clip per
+          wavefront slot -- because its copy is the only one nothing hides; the rest goes in batches of up to ``max_batch_frames``
+          frames, big enough for the engine's cost-ordered launch (``ik_solve``).
+        * out: there is no copy-out.  The kernel writes every frame's qpos straight into the pinned host result (288 B per frame
+          of posted PCIe writes against the ~46 us a wavefront spends on a frame); a fresh pageable result array would cost more in
+          page faults than the kernel takes, a device buffer + copy engine leaves the last batch's copy exposed.
         Results are bitwise those of ``ik_solve`` on resident tensors (same kernel, same per-clip work items).  With ``check``
-        every batch is inspected on the device (non-finite qpos -> FloatingPointError, a capped QP -> RuntimeError).  Returns
-        (qpos [N, nq] float64, iters [N] int32 or None) as numpy arrays backed by pinned memory.  ``out``: the qpos array of an
-        earlier call of the same size, to be overwritten -- page-locking a fresh multi-GB result costs more than the solve (7 GB:
-        0.7 s), so loops over many batches should hand the previous result back (or simply drop it before the next call: the
-        allocator then reuses its pinned block).  Measured rates: DESIGN.md.
+        every batch's solve counts are inspected on the device: bit 31 (a non-finite qpos) -> FloatingPointError, bit 30 (a
+        capped QP) -> RuntimeError.  Returns (qpos [N, nq] float64, iters [N] int32 or None) as numpy arrays backed by pinned
+        memory.  ``out``: the qpos array of an earlier call of the same size, to be overwritten -- page-locking a fresh multi-GB
+        result costs more than the solve (7 GB: 0.7 s), so loops over many batches should hand the previous result back (or
+        simply drop it before the next call: the allocator then reuses its pinned block).  Measured rates: DESIGN.md.
         """
         from .schedule import make_items
         if pos.dtype != quat.dtype or pos.dtype not in (np.float32, np.float64):
@@ -225,17 +230,18 @@ class Engine:
         if N == 0:
             return out.numpy(), (iters.numpy() if want_iters else None)
         n_clips = len(offs) - 1
-        nb = max(1, min(max_batches, n_clips // max(1, min_batch_clips)))
-        bounds = sorted({int(np.searchsorted(offs, N * k / nb, side="left")) for k in range(nb)} | {n_clips})
-        if bounds[0] != 0:
-            bounds = [0] + bounds
+        # batch bounds (clip indices): a first batch of one clip per wavefront slot, then batches of up to max_batch_frames frames
+        slots = 8 * torch.cuda.get_device_properties(self.device).multi_processor_count
+        bounds = [0, min(n_clips, max(1, int(first_batch_clips) if first_batch_clips else slots))]
+        while bounds[-1] < n_clips:
+            nxt = int(np.searchsorted(offs, offs[bounds[-1]] + max(1, int(max_batch_frames)), side="right")) - 1
+            bounds.append(min(n_clips, max(nxt, bounds[-1] + 1)))
         cap = max(int(offs[bounds[k + 1]] - offs[bounds[k]]) for k in range(len(bounds) - 1))
         tpos, tquat = torch.from_numpy(np.ascontiguousarray(pos)), torch.from_numpy(np.ascontiguousarray(quat))
         nbuf = min(2, len(bounds) - 1)
         st = [torch.cuda.Stream(self.device) for _ in range(nbuf)]
         dp = [torch.empty((cap, B, 3), dtype=tdt, device=self.device) for _ in range(nbuf)]
         dq = [torch.empty((cap, B, 4), dtype=tdt, device=self.device) for _ in range(nbuf)]
-        do = [torch.empty((cap, self.nq), dtype=torch.float64, device=self.device) for _ in range(nbuf)]
         want_i = want_iters or check
         di = [torch.empty(cap, dtype=torch.int32, device=self.device) for _ in range(nbuf)] if want_i else None
         flags = torch.zeros((nbuf, 2), dtype=torch.int32, device=self.device)
@@ -247,18 +253,19 @@ class Engine:
             c0, c1 = bounds[k], bounds[k + 1]
             f0, f1 = int(offs[c0]), int(offs[c1])
             n = f1 - f0
+            if n == 0:
+                continue
             items = make_items(offs[c0:c1 + 1] - f0, height_scales=None if hs is None else hs[c0:c1])
             with torch.cuda.stream(st[b]):
                 # pageable -> device: the runtime stages the copy and returns when the host data has been consumed; the other
                 # stream's kernel keeps running meanwhile
                 dp[b][:n].copy_(tpos[f0:f1], non_blocking=True)
                 dq[b][:n].copy_(tquat[f0:f1], non_blocking=True)
-                self.ik_solve(dp[b][:n], dq[b][:n], slot_col, items, params=params, out=do[b][:n],
-                              iters=di[b][:n] if want_i else None, want_iters=want_i)
+                self.ik_solve(dp[b][:n], dq[b][:n], slot_col, items, params=params, out=out[f0:f1], iters=di[b][:n] if want_i else None,
+                              want_iters=want_i, _host_out=True)
                 if check:
-                    flags[b, 0] |= (~torch.isfinite(do[b][:n])).any().to(torch.int32)
-                    flags[b, 1] |= (di[b][:n] >> 30).ne(0).any().to(torch.int32)
-                out[f0:f1].copy_(do[b][:n], non_blocking=True)
+                    flags[b, 0] |= (di[b][:n] >> 31).ne(0).any().to(torch.int32)
+                    flags[b, 1] |= ((di[b][:n] >> 30) & 1).ne(0).any().to(torch.int32)
                 if want_iters:
                     iters[f0:f1].copy_(di[b][:n], non_blocking=True)
         for s_ in st:

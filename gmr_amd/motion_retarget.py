@@ -345,7 +345,7 @@ class GeneralMotionRetargeting:
             items = make_items(offs, chunk=chunk, burn_in=burn_in, height_scales=hs, clip_init=clip_init)
             out, iters, _ = self._engine.ik_solve(tpos, tquat, cols, items, params=self._params(offset_to_ground))
         if check and N > 0:
-            bad = torch.stack([(~torch.isfinite(out)).any(), (iters >> 30).ne(0).any()]).cpu().numpy()
+            bad = torch.stack([(iters >> 31).ne(0).any(), ((iters >> 30) & 1).ne(0).any()]).cpu().numpy()  # flag bits of the solve counts
             if bad[0]:
                 raise FloatingPointError("retarget_batch produced non-finite qpos")
             if bad[1]:

@@ -101,7 +101,8 @@ int gmr_model_info_get(const gmr_model *m, gmr_model_info *out);
  *   qpos_final device, [*][nq] f64 or NULL (rows referenced by items[].final_row)
  *   qpos_out   device, [n_frames][nq] f64; only frames covered by an item's n_out are written
  *   iters_out  device, [n_frames] int32 or NULL: solve_ik calls spent on the frame
- *              (bit 30 set if a QP hit its iteration cap -- never expected)
+ *              (bit 30 set if a QP hit its iteration cap -- never expected; bit 31 if the frame's qpos has a
+ *              non-finite coordinate, e.g. from non-finite key-points: callers can check a batch without reading qpos)
  *   frames_done device, [n_items] int32 or NULL: output frames each item solved (n_out unless a
  *              check_stride item stopped early, see gmr_blob.h)
  *   stream     hipStream_t (as void*), NULL = default stream.  The call is

@@ -612,7 +612,8 @@ def test_one_handle_on_two_streams():
 
 
 def test_host_pipeline_bitwise_equals_resident_path():
-    """Engine.ik_solve_host (host arrays in, pinned host result out, batches alternating between two streams) against ik_solve on
+    """Engine.ik_solve_host (host arrays in, batches alternating between two streams, qpos written by the kernel straight into the
+    pinned host result) against ik_solve on
     resident tensors: same kernel, same per-clip work items -> bitwise equal, whatever the batch split; with the 55-column SMPL-X
     layout (slot_col picks 14 columns on the device) and per-clip heights.  retarget_batch routes big numpy batches through it."""
     from gmr_amd import GeneralMotionRetargeting as GMR
@@ -628,8 +629,8 @@ def test_host_pipeline_bitwise_equals_resident_path():
     hs = np.linspace(0.9, 1.1, len(lens))
     items = make_items(offs, height_scales=hs)
     q_res, it_res, _ = eng.ik_solve(torch.from_numpy(pos).cuda(), torch.from_numpy(quat).cuda(), sc, items)
-    for min_clips, max_b in ((1, 4), (2, 3), (1000, 4)):                     # 4 batches, 3 batches, one batch
-        q, it = eng.ik_solve_host(pos, quat, sc, offs, height_scales=hs, min_batch_clips=min_clips, max_batches=max_b)
+    for first, per in ((2, 60), (1, 1), (3, 10 ** 6), (None, 1 << 25)):        # 2 + 4 batches, one clip each, 3 + the rest, one batch
+        q, it = eng.ik_solve_host(pos, quat, sc, offs, height_scales=hs, first_batch_clips=first, max_batch_frames=per)
         assert np.array_equal(q, q_res.cpu().numpy()) and np.array_equal(it, it_res.cpu().numpy())
     q[:] = 0.0
     q_again, _ = eng.ik_solve_host(pos, quat, sc, offs, height_scales=hs, out=q)   # the previous (pinned) result handed back
