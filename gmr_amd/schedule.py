@@ -40,19 +40,23 @@ def make_items(seq_offsets: Sequence[int], chunk: int = 0, burn_in: int = 0, tra
     hs = np.ones(offs.size - 1) if height_scales is None else np.asarray(height_scales, dtype=np.float64)
     if hs.shape != (offs.size - 1,) or not np.all(np.isfinite(hs)) or np.any(hs <= 0):
         raise ValueError("height_scales must hold one positive factor per clip")
-    rows = []
-    for s in range(offs.size - 1):
-        a, b = int(offs[s]), int(offs[s + 1])
-        if b == a:
-            continue
-        if chunk <= 0:
-            rows.append((a, 0, b - a, clip_init, -1, -1, 0, hs[s]))
-            continue
-        for start in range(a, b, chunk):
-            n_out = min(chunk, b - start)
-            burn = min(burn_in, start - a)
-            rows.append((start - burn, burn, n_out, clip_init if start == a else chunk_init, -1, -1, 0, hs[s]))
-    items = np.array(rows, dtype=WORK_ITEM_DTYPE) if rows else np.zeros(0, dtype=WORK_ITEM_DTYPE)
+    a, b = offs[:-1], offs[1:]
+    keep = b > a  # empty clips have no item
+    a, b, hk = a[keep], b[keep], hs[keep]
+    if chunk <= 0:
+        items = np.zeros(a.size, dtype=WORK_ITEM_DTYPE)
+        items["frame_begin"], items["n_out"], items["init_row"] = a, b - a, clip_init
+    else:
+        nch = (b - a + chunk - 1) // chunk                       # chunks per clip
+        clip = np.repeat(np.arange(a.size), nch)                 # clip of every chunk
+        k = np.arange(int(nch.sum())) - np.repeat(np.cumsum(nch) - nch, nch)  # index of the chunk inside its clip
+        start = a[clip] + k * chunk
+        burn = np.minimum(burn_in, start - a[clip])
+        items = np.zeros(start.size, dtype=WORK_ITEM_DTYPE)
+        items["frame_begin"], items["n_burn"], items["n_out"] = start - burn, burn, np.minimum(chunk, b[clip] - start)
+        items["init_row"] = np.where(k == 0, clip_init, chunk_init)
+        hk = hk[clip]
+    items["final_row"], items["burn_row"], items["check_stride"], items["height_scale"] = -1, -1, 0, hk
     if track:  # final state of item i -> row i, state after burn-in -> row n + i (see plan_walks)
         n = len(items)
         items["final_row"] = np.arange(n)
@@ -72,9 +76,11 @@ def plan_walks(items: np.ndarray, seq_offsets: Sequence[int], chunk: int) -> np.
     last = np.append(first[1:], n)                                                   # one past its last chunk
     multi = last - first > 1
     walks = np.zeros(int(multi.sum()), dtype=WORK_ITEM_DTYPE)
-    for k, (c0, c1) in enumerate(zip(first[multi], last[multi])):
-        clip_end = offs[np.searchsorted(offs, out_begin[c0], side="right")]
-        walks[k] = (out_begin[c0 + 1], 0, int(clip_end - out_begin[c0 + 1]), c0, c0 + 1, n + c0 + 1, chunk, items["height_scale"][c0])
+    c0 = first[multi]
+    clip_end = offs[np.searchsorted(offs, out_begin[c0], side="right")]
+    walks["frame_begin"], walks["n_out"] = out_begin[c0 + 1], clip_end - out_begin[c0 + 1]
+    walks["init_row"], walks["final_row"], walks["burn_row"] = c0, c0 + 1, n + c0 + 1
+    walks["check_stride"], walks["height_scale"] = chunk, items["height_scale"][c0]
     return walks
 
 
