@@ -186,7 +186,7 @@ class Engine:
         return order
 
     def ik_solve_host(self, pos: np.ndarray, quat: np.ndarray, slot_col: np.ndarray, seq_offsets, params: Optional[IKParams] = None,
-                      height_scales=None, first_batch_clips: Optional[int] = None, max_batch_frames: int = 1 << 25, want_iters: bool = True,
+                      height_scales=None, first_batch_clips: Optional[int] = None, max_batch_frames: Optional[int] = None, want_iters: bool = True,
                       check: bool = True, out: Optional[np.ndarray] = None):
         """Whole clips from HOST arrays to a HOST result, pipelined: what the dataset scripts hand over
         (scripts/smplx_to_robot_dataset.py:84-89 builds host key-points per file) without a serial copy-in / solve / copy-out.
@@ -195,7 +195,7 @@ class Engine:
           config consumes on the device), batch by batch, into two alternating device buffers on two HIP streams, so that batch
           k+1 crosses PCIe while batch k's kernel runs.  The first batch is small -- ``first_batch_clips``, by default one clip per
           wavefront slot -- because its copy is the only one nothing hides; the rest goes in batches of up to ``max_batch_frames``
-          frames, big enough for the engine's cost-ordered launch (``ik_solve``).
+          frames (default: what fits 16 GiB of staged key-points per buffer), big enough for the engine's cost-ordered launch.
         * out: there is no copy-out.  The kernel writes every frame's qpos straight into the pinned host result (288 B per frame
           of posted PCIe writes against the ~46 us a wavefront spends on a frame); a fresh pageable result array would cost more in
           page faults than the kernel takes, a device buffer + copy engine leaves the last batch's copy exposed.
@@ -232,9 +232,10 @@ class Engine:
         n_clips = len(offs) - 1
         # batch bounds (clip indices): a first batch of one clip per wavefront slot, then batches of up to max_batch_frames frames
         slots = 8 * torch.cuda.get_device_properties(self.device).multi_processor_count
+        per = max(1, int(max_batch_frames)) if max_batch_frames else max(1, (16 << 30) // (B * 7 * pos.dtype.itemsize))
         bounds = [0, min(n_clips, max(1, int(first_batch_clips) if first_batch_clips else slots))]
         while bounds[-1] < n_clips:
-            nxt = int(np.searchsorted(offs, offs[bounds[-1]] + max(1, int(max_batch_frames)), side="right")) - 1
+            nxt = int(np.searchsorted(offs, offs[bounds[-1]] + per, side="right")) - 1
             bounds.append(min(n_clips, max(nxt, bounds[-1] + 1)))
         cap = max(int(offs[bounds[k + 1]] - offs[bounds[k]]) for k in range(len(bounds) - 1))
         tpos, tquat = torch.from_numpy(np.ascontiguousarray(pos)), torch.from_numpy(np.ascontiguousarray(quat))
