@@ -111,7 +111,11 @@ class GeneralMotionRetargeting:
         damping: float = 5e-1,
         verbose: bool = False,
         device: int = 0,
+        persistent_session_ms: int = 0,
     ) -> None:
+        # persistent_session_ms > 0 (not in the reference's signature): retarget() frames go through a resident wavefront that idles
+        # out after that many milliseconds (gmr_session_set_persistent) -- for a process whose job is the live loop
+        self._persistent_ms = int(persistent_session_ms)
         # robot model (motion_retarget.py:24-27)
         self.xml_file = str(ROBOT_XML_DICT[tgt_robot])
         if verbose:
@@ -203,6 +207,8 @@ class GeneralMotionRetargeting:
         s = self._sessions.get(key)
         if s is None:
             s = self._engine.session(self._columns(names), len(names), self._params(False))
+            if self._persistent_ms > 0:
+                s.set_persistent(self._persistent_ms)
             self._sessions[key] = s
         if key != self._session_key:
             s.reset(self._qpos)

@@ -806,6 +806,13 @@ def test_persistent_session_is_the_batch_solver_fed_frame_by_frame():
     a.close()
     b.close()  # destroyed while the wavefront is resident
     torch.cuda.synchronize()
+    # the class rides on it when asked to
+    from gmr_amd import GeneralMotionRetargeting as GMR
+    g0, g1 = GMR("smplx", "unitree_g1"), GMR("smplx", "unitree_g1", persistent_session_ms=100)
+    for f in range(10):
+        fr = {n: (pos[f, i].astype(np.float64), quat[f, i].astype(np.float64)) for i, n in enumerate(names)}
+        assert np.abs(g0.retarget(dict(fr)) - g1.retarget(dict(fr))).max() < 1e-9
+    g1.setup_retarget_configuration()  # closes the sessions (parks the wavefront)
 
 
 def test_launch_order_by_probe_moves_work_in_time_only():
