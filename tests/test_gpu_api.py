@@ -858,3 +858,12 @@ def test_launch_order_by_probe_moves_work_in_time_only():
     walk = items.copy(); walk["check_stride"][0] = 4
     with pytest.raises(EngineError):
         eng.plan_order(pos, quat, sc, walk)
+    # small and degenerate inputs: one item, three items of different lengths (shorter than the probe), identical clips (one bucket)
+    assert eng.plan_order(pos, quat, sc, items[:1]).cpu().tolist() == [0]
+    short = make_items(np.array([0, 5, 25, 40], dtype=np.int64))
+    assert sorted(eng.plan_order(pos, quat, sc, short).cpu().tolist()) == [0, 1, 2]
+    same = make_items(np.arange(5, dtype=np.int64) * (D * T))  # four items over the same tiled data -> equal cost
+    assert sorted(eng.plan_order(pos, quat, sc, same, probe_frames=8).cpu().tolist()) == [0, 1, 2, 3]
+    q3, _, _ = eng.ik_solve(pos, quat, sc, short, launch_order=eng.plan_order(pos, quat, sc, short))
+    q4, _, _ = eng.ik_solve(pos, quat, sc, short, launch_order=None)
+    assert torch.equal(q3[:40], q4[:40])
