@@ -1716,7 +1716,9 @@ template <int NVP, bool SQ>
 __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const DevModel *__restrict__ mp, IkLaunch L, LdsLayout lay) {
   IkLaunchK *Lk = (IkLaunchK *)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + 8);
   const int *perm = Lk->perm;  // a device-made launch order (gmr_ik_solve_ordered), else items run in array order
-  ik_body<NVP, SQ>(*(DevModelG *)mp, Lk, lay, perm ? __builtin_amdgcn_readfirstlane(perm[blockIdx.x]) : (int)blockIdx.x);
+  const int item = perm ? __builtin_amdgcn_readfirstlane(perm[blockIdx.x]) : (int)blockIdx.x;
+  if ((unsigned)item >= (unsigned)Lk->n_items) return;  // (an order that is not a permutation must not reach outside the item array)
+  ik_body<NVP, SQ>(*(DevModelG *)mp, Lk, lay, item);
 }
 
 // The probe in front of an ordered launch (gmr_ik_plan_order): the first frames of every item, solved for their cost only --

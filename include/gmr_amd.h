@@ -118,7 +118,9 @@ int gmr_ik_solve(gmr_model *m, const void *human_pos, const void *human_quat, in
  *   gmr_ik_plan_order     solves the first probe_frames frames of every item for their cost only (nothing but order_out is
  *                         written) and orders the items by probe solves per frame x frames, most expensive first.
  *                         order_out device int32 [n_items]; other arguments as gmr_ik_solve; plain items only (no check_stride)
- *   gmr_ik_solve_ordered  gmr_ik_solve with workgroup b running item launch_order[b] (device int32 [n_items], a permutation)
+ *   gmr_ik_solve_ordered  gmr_ik_solve with workgroup b running item launch_order[b] (device int32 [n_items]; must be a
+ *                         permutation of 0 .. n_items-1 -- entries outside that range are skipped, a repeated entry leaves another
+ *                         item unsolved)
  * Both are asynchronous on `stream`; results are those of gmr_ik_solve bit for bit (the order only moves work in time).        */
 int gmr_ik_plan_order(gmr_model *m, const void *human_pos, const void *human_quat, int in_dtype, int n_cols, const int32_t *slot_col,
                       int64_t n_frames, const gmr_work_item *items, int n_items, const gmr_ik_params *params, const double *qpos_init,
