@@ -272,6 +272,9 @@ def synth_clips_torch(cm: CompiledModel, lengths, seed: int, device, hard=False,
         z = torch.zeros_like(yaw)
         qpos[:, :, 3:7] = _t_qmul(_t_qmul(_t_qexp(torch.stack([z, z, yaw], -1)), _t_qexp(torch.stack([z, pitch, z], -1))),
                                   _t_qexp(torch.stack([roll, z, z], -1)))
+        if robot.planar_base:  # (as in synth_robot_trajectory: fixed height, heading only)
+            qpos[:, :, 2] = float(robot.body_pos[0, 2])
+            qpos[:, :, 3:7] = _t_qexp(torch.stack([z, z, yaw], -1))
         # FK (MuJoCo convention) for the bodies the tasks need
         q2 = qpos.reshape(s * Tm, robot.nq)
         need = np.zeros(robot.nbody, dtype=bool)
