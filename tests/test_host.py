@@ -326,3 +326,48 @@ def test_c_abi_headers_are_plain_c_and_the_c_example_links(tmp_path):
                            os.path.join(root, "examples", "c_abi_retarget.c"), f"-L{libdir}", "-lgmr_amd", "-L/opt/rocm/lib", "-lamdhip64",
                            f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
     assert exe.exists()
+
+
+def test_make_items_matches_the_plain_loop():
+    """schedule.make_items / plan_walks are vectorised (a LAFAN1-sized chunk plan is ~7 000 rows per call); this is the loop they
+    replace, on random clip sets with empty clips, ragged last chunks, burn-in clipped at the clip start and per-clip heights."""
+    from gmr_amd.schedule import make_items, plan_walks
+    from gmr_amd._native import WORK_ITEM_DTYPE
+    rng = np.random.default_rng(5)
+    for case in range(40):
+        n = int(rng.integers(1, 12))
+        lens = rng.integers(0, 200, n)
+        lens[rng.integers(0, n)] = 0
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        hs = rng.uniform(0.8, 1.2, n)
+        chunk, burn = int(rng.choice([0, 1, 7, 16, 64])), int(rng.choice([0, 3, 24, 100]))
+        ci, ki = int(rng.choice([-1, -2])), int(rng.choice([-1, -2]))
+        rows = []
+        for c in range(n):
+            a, b = int(offs[c]), int(offs[c + 1])
+            if a == b:
+                continue
+            if chunk <= 0:
+                rows.append((a, 0, b - a, ci, -1, -1, 0, hs[c]))
+                continue
+            for start in range(a, b, chunk):
+                bu = min(burn, start - a)
+                rows.append((start - bu, bu, min(chunk, b - start), ci if start == a else ki, -1, -1, 0, hs[c]))
+        ref = np.array(rows, dtype=WORK_ITEM_DTYPE) if rows else np.zeros(0, dtype=WORK_ITEM_DTYPE)
+        got = make_items(offs, chunk=chunk, burn_in=burn, height_scales=hs, chunk_init=ki, clip_init=ci)
+        assert got.dtype == ref.dtype and got.tobytes() == ref.tobytes(), case
+        if chunk > 0 and len(ref):
+            tr = make_items(offs, chunk=chunk, burn_in=burn, track=True, height_scales=hs, chunk_init=ki, clip_init=ci)
+            k = len(tr)
+            assert np.array_equal(tr["final_row"], np.arange(k)) and np.array_equal(tr["burn_row"], k + np.arange(k))
+            walks = plan_walks(tr, offs, chunk)
+            ob = tr["frame_begin"] + tr["n_burn"]
+            exp = []
+            first = [i for i in range(k) if tr["n_burn"][i] == 0 and ob[i] in set(offs[:-1].tolist())]
+            for j, c0 in enumerate(first):
+                c1 = first[j + 1] if j + 1 < len(first) else k
+                if c1 - c0 > 1:
+                    end = int(offs[np.searchsorted(offs, ob[c0], side="right")])
+                    exp.append((int(ob[c0 + 1]), 0, end - int(ob[c0 + 1]), c0, c0 + 1, k + c0 + 1, chunk, tr["height_scale"][c0]))
+            expw = np.array(exp, dtype=WORK_ITEM_DTYPE) if exp else np.zeros(0, dtype=WORK_ITEM_DTYPE)
+            assert walks.tobytes() == expw.tobytes(), case
