@@ -93,6 +93,9 @@ def save_motion(path: str, motion: Dict, override: bool = False) -> bool:
     if os.path.exists(path) and not override:
         return False
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    if str(path).endswith(".pt"):  # the torch twin of the schema (scripts/convert_motion_pkl_to_pt.py:40-48): arrays as tensors
+        torch.save({k: torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v for k, v in motion.items()}, path)
+        return True
     with open(path, "wb") as f:
         pickle.dump(motion, f)
     return True
@@ -100,8 +103,11 @@ def save_motion(path: str, motion: Dict, override: bool = False) -> bool:
 
 def load_robot_motion(motion_file: str):
     """Reader with the contract of general_motion_retargeting/data_loader.py:4-18 (root_rot returned as wxyz)."""
-    with open(motion_file, "rb") as f:
-        d = pickle.load(f)
+    if str(motion_file).endswith(".pt"):  # (:50-58 of the converter: tensors back to arrays; files this package wrote)
+        d = {k: v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v for k, v in torch.load(motion_file, map_location="cpu", weights_only=True).items()}
+    else:
+        with open(motion_file, "rb") as f:
+            d = pickle.load(f)
     root_rot = d["root_rot"][:, [3, 0, 1, 2]]
     return d, d["fps"], d["root_pos"], root_rot, d["dof_pos"], d["local_body_pos"], d["link_body_list"]
 

@@ -371,3 +371,20 @@ def test_make_items_matches_the_plain_loop():
                     exp.append((int(ob[c0 + 1]), 0, end - int(ob[c0 + 1]), c0, c0 + 1, k + c0 + 1, chunk, tr["height_scale"][c0]))
             expw = np.array(exp, dtype=WORK_ITEM_DTYPE) if exp else np.zeros(0, dtype=WORK_ITEM_DTYPE)
             assert walks.tobytes() == expw.tobytes(), case
+
+
+def test_motion_files_pickle_and_torch_twin(tmp_path):
+    """The output wire format (scripts/smplx_to_robot_dataset.py:134-146) and its torch twin (scripts/convert_motion_pkl_to_pt.py):
+    same keys and dtypes back through the reference's reader contract (data_loader.py:4-18), existing files are not overwritten."""
+    from gmr_amd import dataset
+    T = 6
+    rng = np.random.default_rng(0)
+    m = {"fps": 30, "root_pos": rng.random((T, 3)), "root_rot": rng.random((T, 4)), "dof_pos": rng.random((T, 29)),
+         "local_body_pos": rng.random((T, 38, 3)).astype(np.float32), "link_body_list": ["pelvis", "torso"]}
+    for ext in ("pkl", "pt"):
+        p = str(tmp_path / ("clip." + ext))
+        assert dataset.save_motion(p, m) and not dataset.save_motion(p, m) and dataset.save_motion(p, m, override=True)
+        d, fps, rp, rr_wxyz, dp, lb, names = dataset.load_robot_motion(p)
+        assert fps == 30 and names == ["pelvis", "torso"] and lb.dtype == np.float32 and rp.dtype == np.float64
+        assert np.array_equal(rp, m["root_pos"]) and np.array_equal(rr_wxyz, m["root_rot"][:, [3, 0, 1, 2]]) and np.array_equal(dp, m["dof_pos"])
+        assert np.array_equal(lb, m["local_body_pos"]) and set(d) == set(m)
