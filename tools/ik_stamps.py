@@ -23,6 +23,10 @@ ph, qh, _, _, _ = synth.synth_clips(cm, 32, T, seed=2000, hard=True)
 pos = torch.from_numpy(np.concatenate([pe, ph])).cuda().repeat(S // 64, 1, 1)
 quat = torch.from_numpy(np.concatenate([qe, qh])).cuda().repeat(S // 64, 1, 1)
 offs = np.arange(S + 1, dtype=np.int64) * T
+if os.environ.get("STAMP_UNSHAPED"):  # the un-shaped mix of bench.py: distinct clips, any heading, lengths U(T/3, 5T/3), half of them hard
+    T = 900
+    lens = np.random.default_rng(7).integers(T // 3, 5 * T // 3 + 1, size=S)
+    pos, quat, names, offs = synth.synth_clips_torch(cm, lens, seed=4242, device=torch.device("cuda", 0), hard=(np.arange(S) % 2 == 1), yaw0=np.pi)
 eng.ik_solve(pos, quat, cm.slot_columns(names), make_items(offs))
 torch.cuda.synchronize()
 out = (C.c_ulonglong * 16)()
