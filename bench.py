@@ -331,7 +331,7 @@ def main():
                 traffic_source += f"; live PMC pass not taken: {detail}"
         result = {
             "metric": "retargeted frames/sec (whole node), Unitree G1 29-DoF SMPLX; max qpos err vs CPU",
-            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "n1_equivalent_value": value / world, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {
@@ -368,26 +368,87 @@ def main():
                 "valu_frac": un["frames"] / (un["kern_ms"] * 1e-3) * un["solves"] * fsolve / 1e12 / FP64_VECTOR_PEAK_TF,
             }
 
+    # ------------------------------------------------------------------ every N: the CPU path in the same run + parity of rank 0's output
+    #      (rank 0 solves a bounded sample of its own clips with the oracle; the other ranks wait at the barrier that follows)
+    def cpu_leg():
+        from oracle.oracle import Oracle  # checker / comparator only
+        orc = Oracle(cm.blob)
+        cores = host_cores()
+        nc = min(args.cpu_clips if args.cpu_clips > 0 else min(512, max(32, 4 * cores)), S)
+        cp, cq = pos[: nc * T].cpu().numpy(), quat[: nc * T].cpu().numpy()
+        citems = make_items(offs[: nc + 1])
+        one = 4
+        t1 = time.perf_counter()
+        orc.ik_solve(cp[: one * T], cq[: one * T], sc, make_items(offs[: one + 1]), n_threads=1)
+        t_one = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        q_ref, it_ref, _ = orc.ik_solve(cp, cq, sc, citems, n_threads=cores)
+        t_all = time.perf_counter() - t1
+        result["cpu_baseline"] = {
+            "value": nc * T / t_all, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{nc} of rank 0's headline clips x {T} frames, clip-parallel OpenMP on {cores} threads, float64 C oracle" + (f" (timed while the other {world - 1} ranks wait at a barrier)" if world > 1 else ""),
+            "single_core_value": one * T / t_one, "single_core_sample": f"{one} clip(s) x {T} frames",
+            "reference_published": "35-70 frames/s single Python process (README.md:617-620, other hardware, config unstated)",
+        }
+
+        def parity(q_gpu, it_gpu, q_ref, it_ref):
+            d = np.abs(q_gpu - q_ref)
+            # root rotation error as the geodesic angle between the two unit quaternions (SURVEY 8(d))
+            dots = np.abs(np.sum(q_gpu[:, 3:7] * q_ref[:, 3:7], axis=1)) / (
+                np.linalg.norm(q_gpu[:, 3:7], axis=1) * np.linalg.norm(q_ref[:, 3:7], axis=1))
+            geo = 2.0 * np.arccos(np.clip(dots, 0.0, 1.0))
+            return {"max_abs_qpos_err_vs_cpu": float(d.max()), "max_abs_hinge_err_rad": float(d[:, 7:].max()),
+                    "p999_abs_hinge_err_rad": float(np.quantile(d[:, 7:].max(axis=1), 0.999)),
+                    "max_root_pos_err_m": float(np.linalg.norm(q_gpu[:, :3] - q_ref[:, :3], axis=1).max()),
+                    "max_root_geodesic_err_rad": float(geo.max()), "frames_compared": int(q_ref.shape[0]),
+                    "frames_with_different_solve_count": int((it_gpu != it_ref).sum())}
+        result["parity"] = {**parity(out[: nc * T].cpu().numpy(), (iters[: nc * T] & 0x3FFFFFFF).cpu().numpy(), q_ref, it_ref), "tolerance_target_rad": 1e-3}
+        if un is not None:
+            # the un-shaped clips too: the first nc clips in memory order (lengths differ)
+            e = int(uoffs[nc])
+            t1 = time.perf_counter()
+            uq_ref, uit_ref, _ = orc.ik_solve(upos[:e].cpu().numpy(), uquat[:e].cpu().numpy(), usc, make_items(uoffs[: nc + 1]), n_threads=cores)
+            t_u = time.perf_counter() - t1
+            result["parity"]["unshaped"] = parity(uout[:e].cpu().numpy(), (uiters[:e] & 0x3FFFFFFF).cpu().numpy(), uq_ref, uit_ref)
+            result["cpu_baseline"]["unshaped_value"] = e / t_u
+
+    if rank == 0 and not args.no_cpu and not args.hot_only:
+        try:
+            cpu_leg()
+        except Exception as ex:  # (the other ranks are waiting at the barrier below: never leave them there)
+            result["cpu_baseline_error"] = repr(ex)
+    barrier()
+    if un is not None:  # the un-shaped buffers (37 GB of key-points per GPU at the default size) are not needed any more
+        del upos, uquat, uout, uiters
+        torch.cuda.empty_cache()
+
     # ------------------------------------------------------------------ N > 1: the exchange steps, on the real outputs
     if world > 1 and not args.hot_only:
         try:
             cdev = dev if on_rccl else torch.device("cpu")
             ones = torch.ones(1, dtype=torch.float64, device=cdev)
             torch.distributed.all_reduce(ones)
-            # all-gather of qpos (north_star: "allgather of qpos over xGMI"): a bounded sample of this rank's output rows
-            ns_clips = min(S, 1024)
-            lengths = [T] * (ns_clips * world)
+            # all-gather of qpos (north_star: "allgather of qpos over xGMI"): the WHOLE output of every rank -- S clips x T frames x
+            # 288 B per rank -- into global clip order on every rank (gather_rows: slabs of <= 8 GiB received per rank and collective,
+            # one index_copy_ per slab)
+            lengths = np.full(S * world, T, dtype=np.int64)
             mine = gdist.my_clips(lengths)
             local_rows = out[: len(mine) * T]
+            full = torch.empty((S * world * T, eng.nq), dtype=out.dtype, device=cdev)
             torch.cuda.synchronize()
             barrier()
             t0 = time.perf_counter()
-            full = gdist.gather_rows(local_rows, lengths)
+            gdist.gather_rows(local_rows, lengths, out=full)
             torch.cuda.synchronize()
             barrier()
             t_ag = max_over_ranks(time.perf_counter() - t0)
-            ok_rows = bool(full.shape[0] == ns_clips * world * T)
+            # every rank's clips are the same synthetic batch, so global clip i (owner i mod world, its local clip i // world) must
+            # equal this rank's own clip i // world: check a strided sample of clips bit for bit
+            probe = np.unique(np.linspace(0, S * world - 1, 64).astype(np.int64))
+            ok_rows = bool(all(torch.equal(full[i * T:(i + 1) * T].to(out.device), out[(i // world) * T:(i // world + 1) * T]) for i in probe))
             del full
+            if on_rccl:
+                torch.cuda.empty_cache()
             # strong scaling: the SAME S clips split over the ranks (longest-first greedy; equal lengths -> S / world each)
             s_mine = gdist.my_clips([T] * S)
             s_items = make_items(np.arange(len(s_mine) + 1, dtype=np.int64) * T)
@@ -401,7 +462,8 @@ def main():
                     "backend": torch.distributed.get_backend(), "rccl_ranks": int(ones.item()),
                     "allgather_qpos_ms": 1e3 * t_ag, "allgather_rows_per_rank": int(local_rows.shape[0]), "allgather_bytes_per_rank": int(local_rows.shape[0]) * eng.nq * 8,
                     "allgather_GBps_received_per_rank": int(local_rows.shape[0]) * eng.nq * 8 * (world - 1) / t_ag / 1e9, "allgather_complete": ok_rows,
-                    "note": f"gather_rows of {ns_clips} clips x {T} frames of real output per rank (288 B/frame) to every rank; outside the timed region of `value`",
+                    "allgather_rows_total": int(S * world * T),
+                    "note": f"gather_rows of the whole output, {S} clips x {T} frames per rank (288 B/frame), into clip order on every rank; outside the timed region of `value`",
                 }
                 result["strong"] = {"clips_total": S, "frames_per_step": S * T, "value": S * T * args.steps / st_el, "ms_per_step": 1e3 * st_el / args.steps}
                 result["long_clips_sharded"] = {"set": "heading_within_1rad", "clips": len(lc["offs"]) - 1, "frames": int(lc["offs"][-1]), "frames_per_s": 2 * int(lc["offs"][-1]) / lc_el,
@@ -558,47 +620,6 @@ def main():
                                           "serial_pageable = round 1's "
                                           "copy-in / solve / copy-out into a fresh pageable array, no overlap (a quarter of the frames)"}
         del hp_all, hq_all, q_host
-    if rank == 0 and world == 1 and not args.no_cpu and not args.hot_only:
-        from oracle.oracle import Oracle  # checker / comparator only
-        orc = Oracle(cm.blob)
-        cores = host_cores()
-        nc = min(args.cpu_clips if args.cpu_clips > 0 else min(512, max(32, 4 * cores)), S)
-        cp, cq = pos[: nc * T].cpu().numpy(), quat[: nc * T].cpu().numpy()
-        citems = make_items(offs[: nc + 1])
-        one = 4
-        t1 = time.perf_counter()
-        orc.ik_solve(cp[: one * T], cq[: one * T], sc, make_items(offs[: one + 1]), n_threads=1)
-        t_one = time.perf_counter() - t1
-        t1 = time.perf_counter()
-        q_ref, it_ref, _ = orc.ik_solve(cp, cq, sc, citems, n_threads=cores)
-        t_all = time.perf_counter() - t1
-        result["cpu_baseline"] = {
-            "value": nc * T / t_all, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{nc} of the headline workload's clips x {T} frames, clip-parallel OpenMP on {cores} threads, float64 C oracle",
-            "single_core_value": one * T / t_one, "single_core_sample": f"{one} clip(s) x {T} frames",
-            "reference_published": "35-70 frames/s single Python process (README.md:617-620, other hardware, config unstated)",
-        }
-
-        def parity(q_gpu, it_gpu, q_ref, it_ref):
-            d = np.abs(q_gpu - q_ref)
-            # root rotation error as the geodesic angle between the two unit quaternions (SURVEY 8(d))
-            dots = np.abs(np.sum(q_gpu[:, 3:7] * q_ref[:, 3:7], axis=1)) / (
-                np.linalg.norm(q_gpu[:, 3:7], axis=1) * np.linalg.norm(q_ref[:, 3:7], axis=1))
-            geo = 2.0 * np.arccos(np.clip(dots, 0.0, 1.0))
-            return {"max_abs_qpos_err_vs_cpu": float(d.max()), "max_abs_hinge_err_rad": float(d[:, 7:].max()),
-                    "p999_abs_hinge_err_rad": float(np.quantile(d[:, 7:].max(axis=1), 0.999)),
-                    "max_root_pos_err_m": float(np.linalg.norm(q_gpu[:, :3] - q_ref[:, :3], axis=1).max()),
-                    "max_root_geodesic_err_rad": float(geo.max()), "frames_compared": int(q_ref.shape[0]),
-                    "frames_with_different_solve_count": int((it_gpu != it_ref).sum())}
-        result["parity"] = {**parity(out[: nc * T].cpu().numpy(), (iters[: nc * T] & 0x3FFFFFFF).cpu().numpy(), q_ref, it_ref), "tolerance_target_rad": 1e-3}
-        if un is not None:
-            # the un-shaped clips too: the first nc clips in memory order (lengths differ)
-            e = int(uoffs[nc])
-            t1 = time.perf_counter()
-            uq_ref, uit_ref, _ = orc.ik_solve(upos[:e].cpu().numpy(), uquat[:e].cpu().numpy(), usc, make_items(uoffs[: nc + 1]), n_threads=cores)
-            t_u = time.perf_counter() - t1
-            result["parity"]["unshaped"] = parity(uout[:e].cpu().numpy(), (uiters[:e] & 0x3FFFFFFF).cpu().numpy(), uq_ref, uit_ref)
-            result["cpu_baseline"]["unshaped_value"] = e / t_u
     if rank == 0:
         print(json.dumps(result), flush=True)
     barrier()

@@ -67,34 +67,103 @@ def my_clips(lengths: Sequence[int], rank: Optional[int] = None, world: Optional
     return partition_clips(lengths, world)[rank]
 
 
-def gather_rows(local_rows: torch.Tensor, lengths: Sequence[int]) -> torch.Tensor:
+def plan_gather(lengths: Sequence[int], world: int, itemrow_bytes: int, slab_bytes: int):
+    """Host-side plan of ``gather_rows``: clip-level arrays only (nothing per row).
+
+    Returns ``(parts, slabs)``: ``parts[r]`` = clip indices of rank r (``partition_clips``); every slab is a dict with, per rank, the
+    local clip range ``clips[r] = (c0, c1)``, the local row range ``rows[r] = (a, b)`` and ``pad`` = the largest row count among the
+    ranks (what each rank contributes to the collective, zero-padded).  A slab never receives more than ``slab_bytes`` per rank."""
+    ln = np.asarray(lengths, dtype=np.int64).reshape(-1)
+    parts = [np.asarray(p, dtype=np.int64) for p in partition_clips(ln, world)]
+    cum = [np.concatenate([[0], np.cumsum(ln[p])]) for p in parts]      # local row offset of every local clip
+    nloc = max(len(p) for p in parts) if parts else 0
+    rows_cap = max(1, int(slab_bytes) // max(1, world * itemrow_bytes))  # rows one rank may contribute to one slab
+    slabs, c0 = [], 0
+    while c0 < nloc:
+        # the largest c1 with max_r rows(c0:c1) <= rows_cap (at least one clip per slab)
+        c1 = nloc
+        for r in range(world):
+            k0 = min(c0, len(parts[r]))
+            k1 = int(np.searchsorted(cum[r], cum[r][k0] + rows_cap, side="right")) - 1
+            if k1 < len(parts[r]):
+                c1 = min(c1, max(k1, c0 + 1))
+        clips = [(min(c0, len(parts[r])), min(c1, len(parts[r]))) for r in range(world)]
+        rows = [(int(cum[r][a]), int(cum[r][b])) for r, (a, b) in enumerate(clips)]
+        slabs.append({"clips": clips, "rows": rows, "pad": max(b - a for a, b in rows)})
+        c0 = c1
+    return parts, slabs
+
+
+def gather_rows(local_rows: torch.Tensor, lengths: Sequence[int], out: Optional[torch.Tensor] = None, slab_bytes: int = 8 << 30) -> torch.Tensor:
     """All-gather per-rank rows (concatenated clips, in the order of ``my_clips``) into global clip order.
 
-    ``local_rows`` is ``[sum(lengths[i] for i in my_clips), D]``; returns ``[sum(lengths), D]`` on every rank.
-    """
-    lengths = [int(x) for x in lengths]
+    ``local_rows`` is ``[sum(lengths[i] for i in my_clips), D]``; returns ``[sum(lengths), D]`` on every rank (``out`` if given).
+    The host plans per clip (``plan_gather``); rows are placed by ONE ``index_copy_`` per slab on the communication device -- on the
+    clip axis of a ``[clips, T * D]`` view when all clips have the same length T, else on rows through an index expanded on the
+    device (``repeat_interleave``).  Slabs bound the receive buffer (``slab_bytes`` per rank per collective), the result is whole."""
+    ln = np.asarray(lengths, dtype=np.int64).reshape(-1)
     if not dist.is_initialized() or dist.get_world_size() == 1:
+        if out is not None:
+            out.copy_(local_rows)
+            return out
         return local_rows
-    world = dist.get_world_size()
-    parts = partition_clips(lengths, world)
-    counts = [sum(lengths[i] for i in p) for p in parts]
-    if local_rows.shape[0] != counts[dist.get_rank()]:
+    rank, world = dist.get_rank(), dist.get_world_size()
+    D = int(local_rows.shape[1])
+    parts, slabs = plan_gather(ln, world, D * local_rows.element_size(), slab_bytes)
+    if local_rows.shape[0] != int(ln[parts[rank]].sum()):
         raise ValueError("local_rows does not match this rank's clips")
     dev = _comm_device()
-    D = local_rows.shape[1]
-    pad = max(counts)
-    send = torch.zeros((pad, D), dtype=local_rows.dtype, device=dev)
-    send[: local_rows.shape[0]] = local_rows.to(dev)
-    recv = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(recv, send)
-    offs = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
-    out = torch.empty((int(offs[-1]), D), dtype=local_rows.dtype, device=dev)
-    for r, p in enumerate(parts):
-        cur = 0
-        for i in p:
-            out[offs[i]:offs[i + 1]] = recv[r][cur:cur + lengths[i]]
-            cur += lengths[i]
-    return out.to(local_rows.device)
+    total = int(ln.sum())
+    offs = np.concatenate([[0], np.cumsum(ln)]).astype(np.int64)
+    res = out if (out is not None and out.device == dev) else torch.empty((total, D), dtype=local_rows.dtype, device=dev)
+    if res.shape != (total, D) or not res.is_contiguous():
+        raise ValueError("out must be a contiguous [sum(lengths), D] tensor")
+    equal = ln.size > 0 and bool(np.all(ln == ln[0])) and int(ln[0]) > 0
+    T = int(ln[0]) if equal else 0
+    src_all = local_rows if local_rows.device == dev else None
+    for sl in slabs:
+        pad = sl["pad"]
+        if pad == 0:
+            continue
+        a, b = sl["rows"][rank]
+        if src_all is not None and b - a == pad:
+            send = src_all[a:b]                                   # contiguous slice of the caller's rows: no staging copy
+        else:
+            send = torch.zeros((pad, D), dtype=local_rows.dtype, device=dev)
+            send[: b - a] = local_rows[a:b].to(dev)
+        recv = torch.empty((world * pad, D), dtype=local_rows.dtype, device=dev)
+        dist.all_gather_into_tensor(recv, send.contiguous())
+        if equal:
+            # clip axis: received clip (r, j) -> global clip parts[r][c0 + j]
+            k = pad // T
+            src_idx = np.concatenate([r * k + np.arange(c1 - c0) for r, (c0, c1) in enumerate(sl["clips"])])
+            dst_idx = np.concatenate([parts[r][c0:c1] for r, (c0, c1) in enumerate(sl["clips"])])
+            rv = recv.view(world * k, T * D)
+            if len(src_idx) != world * k:
+                rv = rv.index_select(0, torch.from_numpy(src_idx).to(dev))
+            res.view(-1, T * D).index_copy_(0, torch.from_numpy(dst_idx).to(dev), rv)
+        else:
+            # rows: per received clip its length, first source row and first destination row; expanded on the device
+            cl, s0, d0 = [], [], []
+            for r, (c0, c1) in enumerate(sl["clips"]):
+                L = ln[parts[r][c0:c1]]
+                cl.append(L)
+                s0.append(r * pad + np.cumsum(L) - L)
+                d0.append(offs[parts[r][c0:c1]])
+            cl, s0, d0 = (torch.from_numpy(np.concatenate(x)).to(dev) for x in (cl, s0, d0))
+            nrow = int(cl.sum().item())
+            if nrow == 0:
+                continue
+            first = torch.cumsum(cl, 0) - cl                       # position of every clip's first row in the expanded list
+            within = torch.arange(nrow, dtype=torch.int64, device=dev) - torch.repeat_interleave(first, cl)
+            src_rows = torch.repeat_interleave(s0, cl) + within
+            dst_rows = torch.repeat_interleave(d0, cl) + within
+            res.index_copy_(0, dst_rows, recv.index_select(0, src_rows))
+        del recv
+    if out is not None and res is not out:
+        out.copy_(res)
+        return out
+    return res if out is not None else res.to(local_rows.device)
 
 
 # ------------------------------------------------------------------ few, long clips on several GPUs (BASELINE config 3)

@@ -85,12 +85,25 @@ def plan_walks(items: np.ndarray, seq_offsets: Sequence[int], chunk: int) -> np.
 
 
 def partition_clips(lengths: Sequence[int], world_size: int) -> List[List[int]]:
-    """Greedy longest-first assignment of clips to ranks; returns clip indices per rank (each sorted)."""
-    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
-    load = [0] * world_size
-    parts: List[List[int]] = [[] for _ in range(world_size)]
-    for i in order:
-        r = min(range(world_size), key=lambda k: (load[k], k))
-        parts[r].append(i)
-        load[r] += int(lengths[i])
-    return [sorted(p) for p in parts]
+    """Greedy longest-first assignment of clips to ranks; returns clip indices per rank (each sorted).
+
+    Ties go to the lowest clip index and the lowest rank, so equal-length clips are dealt round-robin (clip i -> rank
+    i mod world) -- that case is answered without the greedy loop; the general one runs on a heap (O(n log world))."""
+    import heapq
+    ln = np.asarray(lengths, dtype=np.int64).reshape(-1)
+    n = int(ln.size)
+    if n == 0:
+        return [[] for _ in range(world_size)]
+    if world_size == 1:
+        return [list(range(n))]
+    if np.all(ln == ln[0]) and ln[0] > 0:
+        return [list(range(r, n, world_size)) for r in range(world_size)]
+    order = np.lexsort((np.arange(n), -ln))
+    heap = [(0, r) for r in range(world_size)]
+    owner = np.empty(n, dtype=np.int64)
+    lo = ln.tolist()
+    for i in order.tolist():
+        load, r = heapq.heappop(heap)
+        owner[i] = r
+        heapq.heappush(heap, (load + lo[i], r))
+    return [np.nonzero(owner == r)[0].tolist() for r in range(world_size)]

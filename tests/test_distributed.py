@@ -32,6 +32,16 @@ def _worker(rank, world, port, lengths, q):
     local = torch.cat([torch.arange(offs[i], offs[i + 1], dtype=torch.float64)[:, None].repeat(1, 3) for i in mine]) if mine else torch.zeros((0, 3), dtype=torch.float64)
     full = gdist.gather_rows(local, lengths)
     ok_gather = torch.equal(full[:, 0], torch.arange(offs[-1], dtype=torch.float64))
+    # the same through several slabs (24 bytes per row: at most two rows per rank and collective), into a caller's buffer,
+    # and for equal-length clips (clip-axis placement), with a clip count the ranks do not share evenly
+    buf = torch.full((int(offs[-1]), 3), -1.0, dtype=torch.float64)
+    ok_gather &= gdist.gather_rows(local, lengths, out=buf, slab_bytes=2 * world * 24) is buf
+    ok_gather &= torch.equal(buf[:, 2], torch.arange(offs[-1], dtype=torch.float64))
+    for n_eq, slab in ((7, 8 << 30), (7, 3 * 5 * 24 * world), (8, 5 * 24 * world)):
+        eq = [5] * n_eq
+        mine_eq = gdist.my_clips(eq)
+        loc = torch.cat([torch.arange(5 * i, 5 * i + 5, dtype=torch.float64)[:, None].repeat(1, 3) for i in mine_eq])
+        ok_gather &= torch.equal(gdist.gather_rows(loc, eq, slab_bytes=slab)[:, 1], torch.arange(5 * n_eq, dtype=torch.float64))
     q.put((rank, ok_blob, mine, bool(ok_gather)))
     dist.barrier()
     dist.destroy_process_group()
@@ -54,6 +64,25 @@ def test_broadcast_shard_gather_world2():
     assert sorted(res[0][2] + res[1][2]) == list(range(len(lengths)))
     loads = [sum(lengths[i] for i in r[2]) for r in res]
     assert abs(loads[0] - loads[1]) <= max(lengths)
+
+
+def test_gather_plan_is_per_clip_and_fast():
+    """The host side of gather_rows works on clips, not rows: planning 2 x 8192 clips x 3000 frames (49 M rows) takes milliseconds,
+    equal or unequal lengths; slabs cover every local clip exactly once and respect the byte bound."""
+    import time
+    from gmr_amd.distributed import plan_gather
+    rng = np.random.default_rng(1)
+    for lengths in (np.full(16384, 3000), rng.integers(1000, 5001, size=16384)):
+        t0 = time.perf_counter()
+        parts, slabs = plan_gather(lengths, 2, 288, 1 << 30)
+        dt = time.perf_counter() - t0
+        assert dt < 0.05, dt
+        assert sorted(np.concatenate(parts).tolist()) == list(range(16384))
+        for r in range(2):
+            assert [s["clips"][r][0] for s in slabs][1:] == [s["clips"][r][1] for s in slabs][:-1]
+            assert slabs[0]["clips"][r][0] == 0 and slabs[-1]["clips"][r][1] == len(parts[r])
+            assert slabs[-1]["rows"][r][1] == int(lengths[parts[r]].sum())
+        assert len(slabs) > 1 and all(s["pad"] * 288 * 2 <= (1 << 30) for s in slabs)
 
 
 def _oracle_solver(orc, pos, quat, sc):

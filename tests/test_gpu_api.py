@@ -525,8 +525,15 @@ def test_bench_two_rank_path_rehearsal():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["frames_per_step"] == 2 * 64 * 60
     assert d["value"] > 0 and abs(d["value"] - d["config"]["frames_per_step"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert d["value_unshaped"] > 0 and d["roofline"]["bound"] == "fp64-vector" and d["hbm"]["non_binding"]
+    assert abs(d["n1_equivalent_value"] * 2 - d["value"]) < 1e-6 * d["value"]
+    # the CPU path "in the same run" and rank 0's parity are on the N > 1 line too
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["kernel_ms"] > 0
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    assert d["parity"]["max_abs_qpos_err_vs_cpu"] < 1e-6 and d["parity"]["frames_with_different_solve_count"] == 0
+    assert d["parity"]["unshaped"]["max_abs_qpos_err_vs_cpu"] < 1e-6
     c = d["collectives"]
     assert c["rccl_ranks"] == 2 and c["allgather_complete"] and c["allgather_qpos_ms"] > 0 and c["allgather_bytes_per_rank"] == 64 * 60 * 36 * 8
+    assert c["allgather_rows_total"] == 2 * 64 * 60  # the whole output, not a sample
     assert d["strong"]["clips_total"] == 64 and d["strong"]["value"] > 0
     lc = d["long_clips_sharded"]
     assert lc["ranks"] == 2 and lc["clips"] == 77 and lc["frames_per_s"] > 0 and lc["resolved_frames"] < 0.05 * lc["frames"]  # (initial headings within 1 rad: speculative starts hit the right basin)
