@@ -60,6 +60,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-unshaped", action="store_true", help="skip the un-shaped workload (value_unshaped)")
     ap.add_argument("--hot-only", action="store_true", help="only the warmup + timed launches of the headline workload (no other legs): the "
                     "form profiled under rocprofv3 so the kernel's average duration is that of the timed launch")
+    ap.add_argument("--hot-adapters", action="store_true", help="with --hot-only: also run the two input-adapter kernels (profiles/r03_adapters_*)")
     ap.add_argument("--hot-fk", action="store_true", help="with --hot-only: also run the timed fk_kernel launches (profiles/r02_fk_*)")
     ap.add_argument("--traffic", choices=["auto", "pmc", "const"], default="auto",
                     help="roofline.traffic: 'pmc' measures HBM bytes of ik_kernel in this run (two child rocprofv3 --pmc passes over a short "
@@ -94,39 +95,52 @@ def self_launch(args) -> int:
     return rc if rc != 0 else (0 if line is not None else 1)
 
 
-def measure_traffic_pmc(frames=600, clips=8192, timeout=240):
-    """HBM bytes per frame of ik_kernel from PMC counters, measured now: one child `rocprofv3 --pmc C --kernel-trace` run per counter
-    (they do not fit one pass) over `bench.py --hot-only` with short clips.  Returns (bytes_per_frame, detail) or (None, reason)."""
+ADAPTER_PMC_SIZES = (2_000_000, 500_000)   # (bvh frames, smplx output frames) of the adapters leg inside the PMC child passes
+
+
+def measure_traffic_pmc(frames=600, clips=8192, timeout=300, adapters=True):
+    """HBM bytes from PMC counters, measured now: one child `rocprofv3 --pmc C --kernel-trace` run per counter (they do not fit one
+    pass) over `bench.py --hot-only [--hot-adapters]` with short clips.  Returns (bytes_per_frame of ik_kernel, detail, adapters)
+    -- adapters = {"bvh_fk_kernel": [(FETCH_KB, WRITE_KB) per timed dispatch...], "smplx_keypoints_kernel": [...]} in launch order --
+    or (None, reason, None)."""
     import csv
     import glob
     import shutil
     import tempfile
     prof = shutil.which("rocprofv3")
     if prof is None:
-        return None, "rocprofv3 not found"
+        return None, "rocprofv3 not found", None
     if any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
-        return None, "already under a profiler"
-    vals = {}
+        return None, "already under a profiler", None
+    vals, ad = {}, {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="gmr_pmc_")
         try:
             cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
                    "--hot-only", "--steps", "1", "--warmup", "1", "--frames", str(frames), "--clips", str(clips), "--traffic", "const"]
+            if adapters:
+                cmd.append("--hot-adapters")
             r = subprocess.run(cmd, cwd=tempfile.gettempdir(), env=dict(os.environ, TMPDIR=tempfile.gettempdir()), capture_output=True, text=True, timeout=timeout)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
-                return None, f"{counter} pass failed (rc {r.returncode})"
-            got = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0])) if "ik_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter]
+                return None, f"{counter} pass failed (rc {r.returncode})", None
+            rows = [row for row in csv.DictReader(open(files[0])) if row["Counter_Name"] == counter]
+            rows.sort(key=lambda row: int(row.get("Dispatch_Id", 0) or 0))
+            got = [float(row["Counter_Value"]) for row in rows if "ik_kernel" in row["Kernel_Name"]]
             if not got:
-                return None, f"no ik_kernel rows in the {counter} pass"
+                return None, f"no ik_kernel rows in the {counter} pass", None
             vals[counter] = got[-1]  # the timed launch (the last dispatch); KB
+            for key in ("bvh_fk_kernel", "smplx_keypoints_kernel"):
+                seq = [float(row["Counter_Value"]) for row in rows if key in row["Kernel_Name"]]
+                ad.setdefault(key, {})[counter] = seq[1::2]  # (warm-up, timed) pairs per configuration: the timed ones
         except Exception as ex:  # timeout, parse error: fall back to the committed figure
-            return None, f"{counter} pass: {ex!r}"
+            return None, f"{counter} pass: {ex!r}", None
         finally:
             shutil.rmtree(d, ignore_errors=True)
     n = frames * clips
     bpf = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0 / n  # gfx950 tallies 128-byte read requests at 64 bytes
-    return bpf, {"FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"], "frames_in_pass": n}
+    adapters_kb = {k: list(zip(v.get("FETCH_SIZE", []), v.get("WRITE_SIZE", []))) for k, v in ad.items()} if adapters else None
+    return bpf, {"FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"], "frames_in_pass": n}, adapters_kb
 
 
 def flops_per_solve(cm) -> float:
@@ -173,7 +187,7 @@ def main():
         raise SystemExit(self_launch(args))
     # HBM traffic of the dominant kernel, measured in this run by child profiler passes -- taken first, before this process
     # imports torch or touches the GPU
-    live_traffic = (None, "not requested")
+    live_traffic = (None, "not requested", None)
     if args.traffic == "pmc" or (args.traffic == "auto" and args.gpus == 1 and "WORLD_SIZE" not in os.environ and not args.hot_only):
         live_traffic = measure_traffic_pmc()
 
@@ -323,7 +337,7 @@ def main():
         traffic = (MEASURED_TRAFFIC["bytes_per_frame"] if measured else bpf) * n_frames
         traffic_source = (MEASURED_TRAFFIC["source"] + " (PMC, this configuration) scaled to this launch") if measured else "algorithmic bytes (no PMC pass for this configuration)"
         if live_traffic[1] != "not requested":
-            live, detail = live_traffic
+            live, detail = live_traffic[:2]
             if live is not None:
                 traffic, traffic_source = live * n_frames, {"measured": "this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes over an 8192 x 600 launch, "
                                                                         "(2 x FETCH + WRITE) per frame scaled to this launch", "bytes_per_frame": live, **detail}
@@ -494,6 +508,16 @@ def main():
                                "frac": fk_bytes2 * (nf // 2) / (fk_ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
         del root_pos32, root_rot32, dof32, bp_out, br_out
+    if rank == 0 and world == 1 and (not args.hot_only or args.hot_adapters):
+        # the two input-adapter kernels (rows f-1, f-2): HBM-bound by construction (1.9 - 8.4 KB per frame)
+        if args.hot_only:   # the PMC child passes: one timed dispatch per configuration, smaller arrays
+            adapters_leg(dev, *ADAPTER_PMC_SIZES, steps=1)
+        else:
+            try:
+                result["adapters"] = adapters_leg(dev)
+                attach_adapter_traffic(result["adapters"], live_traffic[2])
+            except Exception as ex:
+                result["adapters"] = {"error": repr(ex)}
     if rank == 0 and world == 1 and not args.hot_only:
         from gmr_amd import dataset
 
@@ -625,6 +649,119 @@ def main():
     barrier()
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def adapters_leg(dev, bvh_frames=4_000_000, smplx_frames_out=1_000_000, steps=3, traffic=None):
+    """The two input-adapter kernels (rows f-1, f-2) against the HBM roofline: gmr::bvh_fk_kernel<1> on LAFAN1-shaped motion rows
+    (22 joints, 3-channel rows, all 24 columns and the 14 bvh_to_g1.json reads) and gmr::smplx_keypoints_kernel on AMASS-shaped
+    SMPL-X arrays (55 of 127 joints, 120 -> 30 fps and 1:1; all 55 columns and the 14 smplx_to_g1.json reads).  Algorithmic bytes
+    per output frame = the input values a frame needs + the output values it produces, each once."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from gmr_amd import _native, synth
+    from gmr_amd.smplx_adapter import SMPLX_JOINT_NAMES, SMPLX_PARENTS
+    lib = _native.load()
+    vp = C.c_void_p
+    st = vp(torch.cuda.current_stream(dev).cuda_stream)
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for a, b in ev:
+            a.record(); fn(); b.record()
+        torch.cuda.synchronize()
+        return float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    def record(kernel, frames, ms, bytes_in, bytes_out, note):
+        bpf = bytes_in + bytes_out
+        gbs = bpf * frames / (ms * 1e-3) / 1e9
+        return {"kernel": kernel, "frames": frames, "kernel_ms": ms, "frames_per_s": frames / (ms * 1e-3), "bytes_per_frame": bpf, "bytes_in": bytes_in, "bytes_out": bytes_out,
+                "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None}, "workload": note}
+
+    out = {}
+    # ---- f-1: BVH rows -> global poses
+    rows, parents, offsets, order = synth.lafan_rows_torch(bvh_frames, dev)
+    J = len(parents)
+    names = [n for n, _, _ in synth.LAFAN1_BONES] + ["LeftFootMod", "RightFootMod"]
+    ep = np.array([names.index("LeftFoot"), names.index("RightFoot")], np.int32)
+    er = np.array([names.index("LeftToe"), names.index("RightToe")], np.int32)
+    od = np.asarray(order, np.int32)
+    d_off = torch.from_numpy(offsets).to(dev)
+    ik_cols = ["Hips", "Spine2", "LeftUpLeg", "RightUpLeg", "LeftLeg", "RightLeg", "LeftFootMod", "RightFootMod", "LeftArm", "RightArm", "LeftForeArm", "RightForeArm", "LeftHand", "RightHand"]
+    for label, cols in (("all_columns", None), ("ik_columns", np.array([names.index(c) for c in ik_cols], np.int32))):
+        B = J + 2 if cols is None else len(cols)
+        pos = torch.empty((bvh_frames, B, 3), dtype=torch.float64, device=dev)
+        quat = torch.empty((bvh_frames, B, 4), dtype=torch.float64, device=dev)
+
+        def run():
+            rc = lib.gmr_bvh_fk_rows(parents.ctypes.data_as(vp), J, od.ctypes.data_as(vp), ep.ctypes.data_as(vp), er.ctypes.data_as(vp), 2, 3, vp(d_off.data_ptr()),
+                                     vp(rows.data_ptr()), int(rows.shape[1]), bvh_frames, 0.01, cols.ctypes.data_as(vp) if cols is not None else None, B,
+                                     vp(pos.data_ptr()), vp(quat.data_ptr()), st)
+            assert rc == 0, rc
+        ms = timed(run)
+        out.setdefault("bvh", {})[label] = record("gmr::bvh_fk_kernel<1>", bvh_frames, ms, (3 + 3 * J) * 8, B * 56,
+                                                  f"LAFAN1-shaped: 22 joints, 3-channel rows in degrees, {B} output columns x (3 + 4) float64")
+        del pos, quat
+    del rows
+    # ---- f-2: SMPL-X arrays -> key-points
+    par = np.asarray(SMPLX_PARENTS, np.int32)
+    Jx, S = len(par), 127
+    live_cols = ["pelvis", "left_hip", "right_hip", "left_knee", "right_knee", "spine3", "left_foot", "right_foot", "left_shoulder", "right_shoulder", "left_elbow", "right_elbow", "left_wrist", "right_wrist"]
+    for mode, skip in (("resample_120_to_30", 4), ("one_to_one", 1)):
+        T_out = smplx_frames_out
+        T = T_out * skip
+        go, fp, jt = synth.smplx_arrays_torch(T, dev, Jx, S)
+        for label, cols in (("all_columns", None), ("ik_columns", np.array([SMPLX_JOINT_NAMES.index(c) for c in live_cols], np.int32))):
+            B = Jx if cols is None else len(cols)
+            if cols is None:
+                n_rot, n_pos = Jx, Jx
+            else:  # rotations of the emitted joints and their ancestors, positions of the emitted joints
+                live = set()
+                for c in cols:
+                    a = int(c)
+                    while a >= 0 and a not in live:
+                        live.add(a)
+                        a = int(par[a])
+                n_rot, n_pos = len(live), len(cols)
+            pos = torch.empty((T_out, B, 3), dtype=torch.float64, device=dev)
+            quat = torch.empty((T_out, B, 4), dtype=torch.float64, device=dev)
+
+            def run():
+                rc = lib.gmr_smplx_keypoints_cols(par.ctypes.data_as(vp), Jx, S, vp(go.data_ptr()), vp(fp.data_ptr()), vp(jt.data_ptr()), T, T_out, int(skip > 1),
+                                                  cols.ctypes.data_as(vp) if cols is not None else None, B, vp(pos.data_ptr()), vp(quat.data_ptr()), st)
+                assert rc == 0, rc
+            ms = timed(run)
+            src_rows = 2 if skip > 1 else 1
+            out.setdefault("smplx", {}).setdefault(mode, {})[label] = record(
+                "gmr::smplx_keypoints_kernel", T_out, ms, src_rows * (n_rot + n_pos) * 24, B * 56,
+                f"AMASS-shaped: 55 joints of a 127-joint position array, {'two source frames per output frame (slerp / lerp)' if skip > 1 else 'one source frame per output frame'}, "
+                f"{n_rot} rotations + {n_pos} positions read, {B} output columns")
+            del pos, quat
+        del go, fp, jt
+    torch.cuda.empty_cache()
+    return out
+
+
+def attach_adapter_traffic(rec, kb):
+    """roofline.traffic of the adapter records from the PMC child passes: (2 x FETCH_SIZE + WRITE_SIZE) per frame of the pass
+    (MI355X_MICROARCH.md "HBM": gfx950 tallies 128-byte read requests at 64 bytes), scaled to the timed launch."""
+    if not kb:
+        return
+    order = [("bvh_fk_kernel", [rec["bvh"]["all_columns"], rec["bvh"]["ik_columns"]], ADAPTER_PMC_SIZES[0]),
+             ("smplx_keypoints_kernel", [rec["smplx"][m][c] for m in ("resample_120_to_30", "one_to_one") for c in ("all_columns", "ik_columns")], ADAPTER_PMC_SIZES[1])]
+    for key, recs, frames_in_pass in order:
+        seq = kb.get(key) or []
+        if len(seq) != len(recs):
+            continue
+        for r, (fetch_kb, write_kb) in zip(recs, seq):
+            bpf = (2.0 * fetch_kb + write_kb) * 1024.0 / frames_in_pass
+            r["roofline"]["traffic"] = bpf * r["frames"]
+            r["roofline"]["traffic_bytes_per_frame"] = bpf
+            r["roofline"]["traffic_over_algorithmic"] = bpf / r["bytes_per_frame"]
+            r["roofline"]["traffic_source"] = {"FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb, "frames_in_pass": frames_in_pass,
+                                               "how": "this run: rocprofv3 --pmc child passes, 2 x FETCH_SIZE + WRITE_SIZE"}
 
 
 def _dataset_device(gmr, dataset, pos, quat, names, offs):

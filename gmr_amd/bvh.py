@@ -6,12 +6,13 @@ channels, the channel count from the last joint's, root translation from the fir
 positions = joint offsets.  Both text stages are native host code of the library: the HIERARCHY section goes through a
 token grammar (``gmr_bvh_parse_header``, gmr_amd/csrc/bvh_text.h), the MOTION block -- the bulk of the file, and the
 regex + float() loop that dominates loading in the reference -- through ``gmr_bvh_parse_motion`` (correctly rounded like
-``float()``); Euler -> quaternion, the quaternion FK, the Y-up -> Z-up turn, cm -> m and the ``LeftFootMod`` /
-``RightFootMod`` synthesis run in one HIP kernel (``gmr_bvh_fk``) and the result stays on the GPU as the
-``[T, B, 3]`` / ``[T, B, 4]`` tensors ``retarget_batch`` consumes -- no per-frame dicts unless asked for.
+``float()``); the parsed rows go to the GPU as they stand, and row slicing (3-, 6- and 9-channel layouts), degrees -> radians,
+Euler -> quaternion, the quaternion FK, the Y-up -> Z-up turn, cm -> m and the ``LeftFootMod`` / ``RightFootMod`` synthesis run in
+one HIP kernel (``gmr_bvh_fk_rows``); the result stays on the GPU as the ``[T, B, 3]`` / ``[T, B, 4]`` tensors ``retarget_batch``
+consumes -- no per-frame dicts unless asked for, and with ``columns=`` only the bones an IK config reads.
 
-Differences from the reference: quaternion signs are not made continuous in time (``remove_quat_discontinuities``
-only flips signs; every consumer is sign-insensitive); 9-channel files are rejected.
+Difference from the reference: quaternion signs are not made continuous in time (``remove_quat_discontinuities``
+only flips signs; every consumer is sign-insensitive).
 """
 from __future__ import annotations
 
@@ -27,14 +28,48 @@ _CHANNEL = {"Xrotation": 0, "Yrotation": 1, "Zrotation": 2}
 
 
 class BvhAnim:
-    def __init__(self, names, parents, offsets, order, positions, eulers_deg, frametime):
+    """One parsed BVH file: the skeleton of the HIERARCHY section and the MOTION rows as they stand in the file (degrees, file
+    units).  ``pos`` / ``eulers_deg`` are the reference's ``Anim`` arrays (extract.py:140-166), sliced from the rows on demand;
+    the GPU path never builds them -- ``gmr_bvh_fk_rows`` reads the rows directly."""
+
+    def __init__(self, names, parents, offsets, order, rows, channels, frametime):
         self.bones: List[str] = names
         self.parents: np.ndarray = parents          # int32 [J]
         self.offsets: np.ndarray = offsets          # [J,3]
         self.order: Tuple[int, int, int] = order    # axis index of the three listed rotation channels
-        self.pos: np.ndarray = positions            # local positions [T,J,3]
-        self.eulers_deg: np.ndarray = eulers_deg    # [T,J,3]
+        self.rows: np.ndarray = rows                # [T, ncol] float64
+        self.channels: int = channels               # 3, 6 or 9 (row layout, include/gmr_amd.h gmr_bvh_fk_rows)
         self.frametime = frametime
+
+    def __len__(self):
+        return int(self.rows.shape[0])
+
+    @property
+    def pos(self) -> np.ndarray:
+        """local positions [T,J,3]"""
+        T, J, data = self.rows.shape[0], len(self.bones), self.rows
+        if self.channels == 6:
+            return data.reshape(T, J, 6)[:, :, 0:3].copy()
+        positions = np.repeat(np.asarray(self.offsets, dtype=np.float64)[None], T, axis=0)
+        positions[:, 0] = data[:, 0:3]
+        if self.channels == 9:
+            # extract.py:152-156: three root position values, then (position, rotation, scale) per non-root joint; a joint's local
+            # position is its offset plus position * scale, the root keeps a zero rotation
+            blk = data[:, 3:].reshape(T, J - 1, 9)
+            positions[:, 1:] += blk[:, :, 0:3] * blk[:, :, 6:9]
+        return positions
+
+    @property
+    def eulers_deg(self) -> np.ndarray:
+        """channel angles [T,J,3], degrees"""
+        T, J, data = self.rows.shape[0], len(self.bones), self.rows
+        if self.channels == 3:
+            return data[:, 3:].reshape(T, J, 3)
+        if self.channels == 6:
+            return data.reshape(T, J, 6)[:, :, 3:6].copy()
+        rotations = np.zeros((T, J, 3))
+        rotations[:, 1:] = data[:, 3:].reshape(T, J - 1, 9)[:, :, 3:6]
+        return rotations
 
 
 def _parse_motion(block: bytes, fnum: int, max_cols: int, filename: str) -> np.ndarray:
@@ -88,34 +123,14 @@ def read_bvh(filename: str) -> BvhAnim:
         raise NotImplementedError(f"{filename}: joints with mixed channel counts are not supported")
     J = len(names)
     data = _parse_motion(motion_block, fnum, 9 * J + 3, filename)  # the ctypes call releases the GIL: files parse in parallel threads
-    offs = np.asarray(offsets, dtype=np.float64)
-    positions = np.repeat(offs[None], fnum, axis=0)
     if channels == 3 and chan[0] == 3:  # a root without translation channels: the reference reads its first three columns as one anyway
         raise NotImplementedError(f"{filename}: a 3-channel root is not supported")
-    if channels == 3:
-        if data.shape[1] != 3 + 3 * J:
-            raise ValueError(f"{filename}: expected {3 + 3 * J} columns, found {data.shape[1]}")
-        positions[:, 0] = data[:, 0:3]
-        rotations = data[:, 3:].reshape(fnum, J, 3)
-    elif channels == 6:
-        if data.shape[1] != 6 * J:
-            raise ValueError(f"{filename}: expected {6 * J} columns, found {data.shape[1]}")
-        blk = data.reshape(fnum, J, 6)
-        positions = blk[:, :, 0:3].copy()
-        rotations = blk[:, :, 3:6].copy()
-    elif channels == 9:
-        # extract.py:152-156: three root position values, then (position, rotation, scale) per non-root joint; a joint's local
-        # position is its offset plus position * scale, the root keeps a zero rotation
-        if len(names) < 2 or data.shape[1] != 3 + 9 * (J - 1):
-            raise ValueError(f"{filename}: expected {3 + 9 * (J - 1)} columns, found {data.shape[1]}")
-        positions[:, 0] = data[:, 0:3]
-        blk = data[:, 3:].reshape(fnum, J - 1, 9)
-        positions[:, 1:] += blk[:, :, 0:3] * blk[:, :, 6:9]
-        rotations = np.zeros((fnum, J, 3))
-        rotations[:, 1:] = blk[:, :, 3:6]
-    else:
+    if channels not in (3, 6, 9):
         raise NotImplementedError(f"{filename}: {channels}-channel joints are not supported")
-    return BvhAnim(names, np.asarray(parents, dtype=np.int32), offs, order, positions, rotations, frametime)
+    want = {3: 3 + 3 * J, 6: 6 * J, 9: 3 + 9 * (J - 1)}[channels]
+    if (channels == 9 and J < 2) or data.shape[1] != want:
+        raise ValueError(f"{filename}: expected {want} columns, found {data.shape[1]}")
+    return BvhAnim(names, np.asarray(parents, dtype=np.int32), np.asarray(offsets, dtype=np.float64), order, data, channels, frametime)
 
 
 class BvhClip:
@@ -148,37 +163,92 @@ def _estimate_height(last: Dict[str, np.ndarray]) -> float:
     return float(h)
 
 
-def load_lafan1_file(bvh_file: str, device: int = 0) -> BvhClip:
-    """BVH file -> global poses (metres, Z-up, wxyz) on ``cuda:device`` + the reference's height estimate."""
-    anim = read_bvh(bvh_file)
-    lib = _native.load()
-    dev = torch.device("cuda", device)
-    T, J = anim.pos.shape[0], len(anim.bones)
-    extra_names, extra_pos, extra_rot = [], [], []
+def _foot_mods(bones: List[str]):
+    """lafan1.py:36-39: LeftFootMod / RightFootMod = the foot's position with the toe's orientation."""
+    names, pos_src, rot_src = [], [], []
     for side in ("Left", "Right"):
-        if f"{side}Foot" in anim.bones and f"{side}Toe" in anim.bones:  # lafan1.py:36-39
-            extra_names.append(f"{side}FootMod")
-            extra_pos.append(anim.bones.index(f"{side}Foot"))
-            extra_rot.append(anim.bones.index(f"{side}Toe"))
+        if f"{side}Foot" in bones and f"{side}Toe" in bones:
+            names.append(f"{side}FootMod")
+            pos_src.append(bones.index(f"{side}Foot"))
+            rot_src.append(bones.index(f"{side}Toe"))
+    return names, pos_src, rot_src
+
+
+def _device_fk(a0: BvhAnim, rows: torch.Tensor, dev: torch.device, columns=None):
+    """``gmr_bvh_fk_rows`` on motion rows already on the device (all of one skeleton).  ``columns``: names to emit (joints or
+    FootMod entries, in this order) or None for everything.  Returns (pos [N,B,3], quat [N,B,4], names)."""
+    lib = _native.load()
+    N, J = int(rows.shape[0]), len(a0.bones)
+    extra_names, extra_pos, extra_rot = _foot_mods(a0.bones)
     E = len(extra_names)
-    lp = torch.from_numpy(np.ascontiguousarray(anim.pos)).to(dev)
-    er = torch.from_numpy(np.ascontiguousarray(np.radians(anim.eulers_deg))).to(dev)
-    pos = torch.empty((T, J + E, 3), dtype=torch.float64, device=dev)
-    quat = torch.empty((T, J + E, 4), dtype=torch.float64, device=dev)
-    parents = np.ascontiguousarray(anim.parents, dtype=np.int32)
-    order = np.asarray(anim.order, dtype=np.int32)
-    ep, erot = np.asarray(extra_pos, dtype=np.int32), np.asarray(extra_rot, dtype=np.int32)
-    vp = C.c_void_p
-    rc = lib.gmr_bvh_fk(parents.ctypes.data_as(vp), J, order.ctypes.data_as(vp), ep.ctypes.data_as(vp) if E else None,
-                        erot.ctypes.data_as(vp) if E else None, E, vp(lp.data_ptr()), vp(er.data_ptr()), T, 0.01,
-                        vp(pos.data_ptr()), vp(quat.data_ptr()), vp(torch.cuda.current_stream(dev).cuda_stream))
-    if rc != 0:
-        raise RuntimeError(f"gmr_bvh_fk failed with status {rc} ({J} joints, {E} extra)")
-    names = list(anim.bones) + extra_names
-    height = 1.75
-    if T > 0:
-        last = pos[-1].cpu().numpy()
-        height = _estimate_height({n: last[i] for i, n in enumerate(names)})
+    all_names = list(a0.bones) + extra_names
+    if columns is None:
+        names, cols, B = all_names, None, J + E
+    else:
+        names = [str(c) for c in columns]
+        try:
+            cols = np.asarray([all_names.index(c) for c in names], dtype=np.int32)
+        except ValueError as ex:
+            raise KeyError(f"{ex.args[0].split(' is not')[0]}: no such bone in the BVH skeleton") from None
+        B = len(names)
+    pos = torch.empty((N, B, 3), dtype=torch.float64, device=dev)
+    quat = torch.empty((N, B, 4), dtype=torch.float64, device=dev)
+    if N > 0:
+        parents = np.ascontiguousarray(a0.parents, dtype=np.int32)
+        order = np.asarray(a0.order, dtype=np.int32)
+        ep, erot = np.asarray(extra_pos, dtype=np.int32), np.asarray(extra_rot, dtype=np.int32)
+        offs_d = torch.from_numpy(np.ascontiguousarray(a0.offsets, dtype=np.float64)).to(dev)
+        vp = C.c_void_p
+        rc = lib.gmr_bvh_fk_rows(parents.ctypes.data_as(vp), J, order.ctypes.data_as(vp), ep.ctypes.data_as(vp) if E else None,
+                                 erot.ctypes.data_as(vp) if E else None, E, int(a0.channels), vp(offs_d.data_ptr()), vp(rows.data_ptr()),
+                                 int(rows.shape[1]), N, 0.01, cols.ctypes.data_as(vp) if cols is not None else None, B,
+                                 vp(pos.data_ptr()), vp(quat.data_ptr()), vp(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"gmr_bvh_fk_rows failed with status {rc} ({J} joints, {E} extra, {a0.channels}-channel rows)")
+    return pos, quat, names
+
+
+def _height_columns(a0: BvhAnim) -> List[str]:
+    """The entries the height estimate of lafan1.py:45-69 looks at (all of them when there is no Head)."""
+    extra_names, _, _ = _foot_mods(a0.bones)
+    if "Head" not in a0.bones:
+        return list(a0.bones) + extra_names
+    return ["Head"] + [k for k in ("LeftFootMod", "RightFootMod", "LeftFoot", "RightFoot") if k in a0.bones or k in extra_names]
+
+
+def _clip_heights(a0: BvhAnim, rows: torch.Tensor, offs: np.ndarray, dev: torch.device, full=None) -> List[float]:
+    """lafan1.py:45-69 per clip, from each clip's own last frame (the few last rows go through the FK kernel once more when the
+    batch was emitted with a column selection)."""
+    lens = np.diff(offs)
+    if int(lens.sum()) == 0:
+        return [1.75] * len(lens)
+    last_rows = torch.from_numpy(offs[1:][lens > 0] - 1).to(dev)
+    if full is not None:
+        pos, names = full
+        last = pos[last_rows].cpu().numpy()
+    else:
+        names = _height_columns(a0)
+        last, _, _ = _device_fk(a0, rows[last_rows].contiguous(), dev, names)
+        last = last.cpu().numpy()
+    heights, k = [], 0
+    for n in lens:
+        if n == 0:
+            heights.append(1.75)
+            continue
+        heights.append(_estimate_height({nm: last[k, i] for i, nm in enumerate(names)}))
+        k += 1
+    return heights
+
+
+def load_lafan1_file(bvh_file: str, device: int = 0, columns=None) -> BvhClip:
+    """BVH file -> global poses (metres, Z-up, wxyz) on ``cuda:device`` + the reference's height estimate.
+    ``columns``: emit only these entries (e.g. the bones an IK config consumes), in this order."""
+    anim = read_bvh(bvh_file)
+    dev = torch.device("cuda", device)
+    rows = torch.from_numpy(np.ascontiguousarray(anim.rows)).to(dev)
+    pos, quat, names = _device_fk(anim, rows, dev, columns)
+    offs = np.array([0, len(anim)], dtype=np.int64)
+    height = _clip_heights(anim, rows, offs, dev, full=(pos, names) if columns is None else None)[0]
     return BvhClip(pos, quat, names, height, anim.frametime)
 
 
@@ -194,13 +264,21 @@ class BvhBatch:
         return len(self.files)
 
 
-def load_lafan1_files(bvh_files, device: int = 0, threads: int = 8) -> BvhBatch:
+def _check_one_skeleton(files, anims):
+    a0 = anims[0]
+    for f, a in zip(files, anims):
+        if a.bones != a0.bones or not np.array_equal(a.parents, a0.parents) or a.order != a0.order or a.channels != a0.channels \
+                or not np.array_equal(a.offsets, a0.offsets):
+            raise ValueError(f"{f}: skeleton differs from {files[0]} (one batch = one skeleton)")
+
+
+def load_lafan1_files(bvh_files, device: int = 0, threads: int = 8, columns=None) -> BvhBatch:
     """A folder's worth of BVH files -> one GPU batch (the file loop of scripts/bvh_to_robot_dataset.py:59-80, where every file
     is parsed with regexes and turned into per-frame dicts one after the other).  The text of the files is parsed on ``threads``
-    host threads (both native parsers release the GIL), the clips are concatenated, and ONE ``gmr_bvh_fk`` launch does Euler ->
-    quaternion, the skeleton FK, Y-up -> Z-up, cm -> m and the FootMod synthesis for all of them.  All files must share one
-    skeleton (names, parents, Euler order), as a dataset does; the height estimate of every clip (lafan1.py:45-69, from its own
-    last frame) comes back with the batch."""
+    host threads (both native parsers release the GIL) straight into one pinned row array, and ONE ``gmr_bvh_fk_rows`` launch does
+    row slicing, degrees -> radians, Euler -> quaternion, the skeleton FK, Y-up -> Z-up, cm -> m and the FootMod synthesis for all
+    of them.  All files must share one skeleton (names, parents, offsets, Euler order, channel layout), as a dataset does; the
+    height estimate of every clip (lafan1.py:45-69, from its own last frame) comes back with the batch."""
     from concurrent.futures import ThreadPoolExecutor
     files = [str(f) for f in bvh_files]
     if not files:
@@ -208,51 +286,15 @@ def load_lafan1_files(bvh_files, device: int = 0, threads: int = 8) -> BvhBatch:
     with ThreadPoolExecutor(max_workers=max(1, min(threads, len(files)))) as ex:
         anims = list(ex.map(read_bvh, files))
     a0 = anims[0]
-    for f, a in zip(files, anims):
-        if a.bones != a0.bones or not np.array_equal(a.parents, a0.parents) or a.order != a0.order:
-            raise ValueError(f"{f}: skeleton differs from {files[0]} (one batch = one skeleton)")
-    lib = _native.load()
+    _check_one_skeleton(files, anims)
     dev = torch.device("cuda", device)
-    lens = np.array([a.pos.shape[0] for a in anims], dtype=np.int64)
+    lens = np.array([len(a) for a in anims], dtype=np.int64)
     offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-    N, J = int(offs[-1]), len(a0.bones)
-    extra_names, extra_pos, extra_rot = [], [], []
-    for side in ("Left", "Right"):
-        if f"{side}Foot" in a0.bones and f"{side}Toe" in a0.bones:  # lafan1.py:36-39
-            extra_names.append(f"{side}FootMod")
-            extra_pos.append(a0.bones.index(f"{side}Foot"))
-            extra_rot.append(a0.bones.index(f"{side}Toe"))
-    E = len(extra_names)
-    lp_h = torch.empty((N, J, 3), dtype=torch.float64, pin_memory=True)
-    er_h = torch.empty((N, J, 3), dtype=torch.float64, pin_memory=True)
+    N, ncol = int(offs[-1]), int(a0.rows.shape[1])
+    rows_h = torch.empty((N, ncol), dtype=torch.float64, pin_memory=True)
     for a, o in zip(anims, offs[:-1]):
-        n = a.pos.shape[0]
-        lp_h[o:o + n] = torch.from_numpy(a.pos)
-        np.radians(a.eulers_deg, out=er_h[o:o + n].numpy())
-    lp, er = lp_h.to(dev, non_blocking=True), er_h.to(dev, non_blocking=True)
-    pos = torch.empty((N, J + E, 3), dtype=torch.float64, device=dev)
-    quat = torch.empty((N, J + E, 4), dtype=torch.float64, device=dev)
-    names = list(a0.bones) + extra_names
-    if N > 0:
-        parents = np.ascontiguousarray(a0.parents, dtype=np.int32)
-        order = np.asarray(a0.order, dtype=np.int32)
-        ep, erot = np.asarray(extra_pos, dtype=np.int32), np.asarray(extra_rot, dtype=np.int32)
-        vp = C.c_void_p
-        rc = lib.gmr_bvh_fk(parents.ctypes.data_as(vp), J, order.ctypes.data_as(vp), ep.ctypes.data_as(vp) if E else None,
-                            erot.ctypes.data_as(vp) if E else None, E, vp(lp.data_ptr()), vp(er.data_ptr()), N, 0.01,
-                            vp(pos.data_ptr()), vp(quat.data_ptr()), vp(torch.cuda.current_stream(dev).cuda_stream))
-        if rc != 0:
-            raise RuntimeError(f"gmr_bvh_fk failed with status {rc} ({J} joints, {E} extra)")
-    heights = []
-    if N > 0:
-        last = pos[torch.from_numpy(offs[1:][lens > 0] - 1).to(dev)].cpu().numpy()  # every clip's last frame
-        k = 0
-        for n in lens:
-            if n == 0:
-                heights.append(1.75)
-                continue
-            heights.append(_estimate_height({nm: last[k, i] for i, nm in enumerate(names)}))
-            k += 1
-    else:
-        heights = [1.75] * len(files)
+        rows_h[o:o + len(a)] = torch.from_numpy(a.rows)
+    rows = rows_h.to(dev, non_blocking=True)
+    pos, quat, names = _device_fk(a0, rows, dev, columns)
+    heights = _clip_heights(a0, rows, offs, dev, full=(pos, names) if columns is None else None)
     return BvhBatch(pos, quat, names, offs, heights, [a.frametime for a in anims], files)

@@ -17,9 +17,9 @@
 #include <string>
 #include <vector>
 
-#include "bvh_kernel.hip.h"
 #include "fk_kernel.hip.h"
 #include "ik_kernel.hip.h"
+#include "bvh_kernel.hip.h"
 #include "smplx_kernel.hip.h"
 #include "bvh_text.h"
 
@@ -1443,9 +1443,19 @@ int gmr_fk_min_height(gmr_model *m, const float *root_pos, const float *root_rot
   return GMR_OK;
 }
 
-int gmr_smplx_keypoints(const int32_t *parents, int n_joints, int joints_stride, const double *global_orient, const double *full_pose,
-                        const double *joints, int64_t n_frames, int64_t n_frames_out, int resample, double *pos_out, double *quat_out,
-                        void *stream) {
+/* Frames per wavefront of the adapter kernels: runs long enough that a wavefront's setup (plan, tables) is amortised and its
+ * consecutive output rows complete each other's cache lines, short enough that a small clip still fills the chip. */
+static int adapter_chunk(int64_t n_frames, int groups) {
+  int64_t c = (n_frames + 16383) / 16384;  /* ~16 k wavefronts = 16 per SIMD on 256 CUs when there is that much work */
+  c = std::max<int64_t>(c, 8);
+  c = std::min<int64_t>(c, 64);
+  c = (c + groups - 1) / groups * groups;
+  return (int)c;
+}
+
+int gmr_smplx_keypoints_cols(const int32_t *parents, int n_joints, int joints_stride, const double *global_orient, const double *full_pose,
+                             const double *joints, int64_t n_frames, int64_t n_frames_out, int resample, const int32_t *out_cols, int n_out,
+                             double *pos_out, double *quat_out, void *stream) {
   if (!parents || !global_orient || !full_pose || !joints || !pos_out || !quat_out || n_frames < 0 || n_frames_out < 0) return GMR_EINVAL;
   if (n_joints < 1 || n_joints > gmr::kSmplMaxJoints || joints_stride < n_joints) return GMR_EUNSUPPORTED;
   if (!resample && n_frames_out != n_frames) return GMR_EINVAL;
@@ -1457,12 +1467,34 @@ int gmr_smplx_keypoints(const int32_t *parents, int n_joints, int joints_stride,
     if (j > 0 && (parents[j] < 0 || parents[j] >= j)) return GMR_EINVAL;
     sk.parent[j] = (short)parents[j];
   }
+  if (out_cols) {  /* out_cols[c] = joint emitted as column c; ancestors are chained internally */
+    if (n_out < 1 || n_out > n_joints) return GMR_EINVAL;
+    for (int j = 0; j < n_joints; ++j) { sk.out_col[j] = -1; sk.live[j] = 0; }
+    for (int c = 0; c < n_out; ++c) {
+      const int j = out_cols[c];
+      if (j < 0 || j >= n_joints || sk.out_col[j] >= 0) return GMR_EINVAL;
+      sk.out_col[j] = (short)c;
+      for (int a = j; a >= 0 && !sk.live[a]; a = parents[a]) sk.live[a] = 1;
+    }
+    sk.n_out = n_out;
+  } else {
+    for (int j = 0; j < n_joints; ++j) { sk.out_col[j] = (short)j; sk.live[j] = 1; }
+    sk.n_out = n_joints;
+  }
   if (n_frames_out == 0) return GMR_OK;
-  const int64_t nblk = (n_frames_out + 127) / 128;
+  const int chunk = adapter_chunk(n_frames_out, gmr::chain_geom(n_joints).groups);
+  const int64_t nblk = (n_frames_out + chunk - 1) / chunk;
   if (nblk > 0x7fffffff) return GMR_EINVAL;
-  hipLaunchKernelGGL(gmr::smplx_keypoints_kernel, dim3((unsigned)nblk), dim3(128), 0, static_cast<hipStream_t>(stream), sk, global_orient,
-                     full_pose, joints, n_frames, n_frames_out, pos_out, quat_out);
+  hipLaunchKernelGGL(gmr::smplx_keypoints_kernel, dim3((unsigned)nblk), dim3(64), 0, static_cast<hipStream_t>(stream), sk, global_orient,
+                     full_pose, joints, n_frames, n_frames_out, chunk, pos_out, quat_out);
   return hipGetLastError() == hipSuccess ? GMR_OK : GMR_EDEVICE;
+}
+
+int gmr_smplx_keypoints(const int32_t *parents, int n_joints, int joints_stride, const double *global_orient, const double *full_pose,
+                        const double *joints, int64_t n_frames, int64_t n_frames_out, int resample, double *pos_out, double *quat_out,
+                        void *stream) {
+  return gmr_smplx_keypoints_cols(parents, n_joints, joints_stride, global_orient, full_pose, joints, n_frames, n_frames_out, resample,
+                                  nullptr, 0, pos_out, quat_out, stream);
 }
 
 int gmr_bvh_parse_header(const char *text, size_t len, int max_joints, char *names_out, size_t names_cap, int32_t *parents_out,
@@ -1566,14 +1598,15 @@ int64_t gmr_bvh_parse_motion(const char *text, size_t len, int64_t max_lines, do
   return count;
 }
 
-int gmr_bvh_fk(const int32_t *parents, int n_joints, const int32_t *euler_order, const int32_t *extra_pos_src,
-               const int32_t *extra_rot_src, int n_extra, const double *local_pos, const double *euler_rad, int64_t n_frames,
-               double scale, double *pos_out, double *quat_out, void *stream) {
-  if (!parents || !euler_order || !local_pos || !euler_rad || !pos_out || !quat_out || n_frames < 0) return GMR_EINVAL;
+static int bvh_fk_launch(const int32_t *parents, int n_joints, const int32_t *euler_order, const int32_t *extra_pos_src,
+                         const int32_t *extra_rot_src, int n_extra, int layout, const double *pbase, const double *rbase,
+                         const double *offsets, int64_t pstride, int64_t rstride, double ang_scale, int64_t n_frames, double scale,
+                         const int32_t *out_cols, int n_out, double *pos_out, double *quat_out, void *stream) {
+  if (!parents || !euler_order || !pbase || !rbase || !pos_out || !quat_out || n_frames < 0) return GMR_EINVAL;
   if (n_joints < 1 || n_joints > gmr::kBvhMaxJoints || n_extra < 0 || n_extra > gmr::kBvhMaxExtra) return GMR_EUNSUPPORTED;
   if (n_extra > 0 && (!extra_pos_src || !extra_rot_src)) return GMR_EINVAL;
   gmr::BvhSkeleton sk{};
-  sk.n_joints = n_joints; sk.n_extra = n_extra;
+  sk.n_joints = n_joints; sk.n_extra = n_extra; sk.layout = layout;
   for (int i = 0; i < 3; ++i) {
     if (euler_order[i] < 0 || euler_order[i] > 2) return GMR_EINVAL;
     sk.order[i] = euler_order[i];
@@ -1587,12 +1620,63 @@ int gmr_bvh_fk(const int32_t *parents, int n_joints, const int32_t *euler_order,
     if (extra_pos_src[k] < 0 || extra_pos_src[k] >= n_joints || extra_rot_src[k] < 0 || extra_rot_src[k] >= n_joints) return GMR_EINVAL;
     sk.extra_pos_src[k] = (short)extra_pos_src[k]; sk.extra_rot_src[k] = (short)extra_rot_src[k];
   }
+  const int nb = n_joints + n_extra;
+  if (out_cols) {  /* out_cols[c] = entry (joint, or n_joints + extra) emitted as column c */
+    if (n_out < 1 || n_out > nb) return GMR_EINVAL;
+    for (int j = 0; j < n_joints; ++j) sk.out_col[j] = -1;
+    for (int k = 0; k < n_extra; ++k) sk.extra_col[k] = -1;
+    for (int c = 0; c < n_out; ++c) {
+      const int e = out_cols[c];
+      if (e < 0 || e >= nb) return GMR_EINVAL;
+      short &slot = e < n_joints ? sk.out_col[e] : sk.extra_col[e - n_joints];
+      if (slot >= 0) return GMR_EINVAL;
+      slot = (short)c;
+    }
+    sk.n_out = n_out;
+  } else {
+    for (int j = 0; j < n_joints; ++j) sk.out_col[j] = (short)j;
+    for (int k = 0; k < n_extra; ++k) sk.extra_col[k] = (short)(n_joints + k);
+    sk.n_out = nb;
+  }
   if (n_frames == 0) return GMR_OK;
-  const int64_t nblk = (n_frames + 127) / 128;
+  const gmr::ChainGeom geo = gmr::chain_geom(n_joints);
+  const int chunk = adapter_chunk(n_frames, geo.groups);
+  const int64_t nblk = (n_frames + chunk - 1) / chunk;
   if (nblk > 0x7fffffff) return GMR_EINVAL;
-  hipLaunchKernelGGL(gmr::bvh_fk_kernel, dim3((unsigned)nblk), dim3(128), 0, static_cast<hipStream_t>(stream), sk, local_pos, euler_rad,
-                     n_frames, scale, pos_out, quat_out);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int K = geo.jp <= 64 ? 1 : geo.jp / 64;
+#define GMR_BVH_LAUNCH(KK, SS)                                                                                                              \
+  hipLaunchKernelGGL((gmr::bvh_fk_kernel<KK, SS>), dim3((unsigned)nblk), dim3(64), lds_bytes, st, sk, pbase, rbase, offsets, (int)pstride, (int)rstride, ang_scale, \
+                     n_frames, chunk, scale, pos_out, quat_out)
+  const bool s9 = layout == gmr::BVH_ROWS9;
+  const int per_frame = (int)(pbase != rbase ? pstride + rstride : pstride);
+  const size_t lds_bytes = 2 * (size_t)gmr::bvh_batch(per_frame, geo.groups).doubles * sizeof(double);  // two stage buffers
+  if (K == 1) { if (s9) GMR_BVH_LAUNCH(1, true); else GMR_BVH_LAUNCH(1, false); }
+  else if (K == 2) { if (s9) GMR_BVH_LAUNCH(2, true); else GMR_BVH_LAUNCH(2, false); }
+  else { if (s9) GMR_BVH_LAUNCH(3, true); else GMR_BVH_LAUNCH(3, false); }
+#undef GMR_BVH_LAUNCH
   return hipGetLastError() == hipSuccess ? GMR_OK : GMR_EDEVICE;
+}
+
+int gmr_bvh_fk(const int32_t *parents, int n_joints, const int32_t *euler_order, const int32_t *extra_pos_src,
+               const int32_t *extra_rot_src, int n_extra, const double *local_pos, const double *euler_rad, int64_t n_frames,
+               double scale, double *pos_out, double *quat_out, void *stream) {
+  return bvh_fk_launch(parents, n_joints, euler_order, extra_pos_src, extra_rot_src, n_extra, gmr::BVH_SPLIT, local_pos, euler_rad, nullptr,
+                       3 * (int64_t)n_joints, 3 * (int64_t)n_joints, 1.0, n_frames, scale, nullptr, 0, pos_out, quat_out, stream);
+}
+
+int gmr_bvh_fk_rows(const int32_t *parents, int n_joints, const int32_t *euler_order, const int32_t *extra_pos_src,
+                    const int32_t *extra_rot_src, int n_extra, int channels, const double *offsets, const double *rows, int64_t n_cols,
+                    int64_t n_frames, double scale, const int32_t *out_cols, int n_out, double *pos_out, double *quat_out, void *stream) {
+  if (!offsets || n_joints < 1) return GMR_EINVAL;
+  int64_t want;
+  if (channels == 3) want = 3 + 3 * (int64_t)n_joints;
+  else if (channels == 6) want = 6 * (int64_t)n_joints;
+  else if (channels == 9) want = 3 + 9 * (int64_t)(n_joints - 1);
+  else return GMR_EUNSUPPORTED;
+  if (n_cols != want) return GMR_EINVAL;
+  return bvh_fk_launch(parents, n_joints, euler_order, extra_pos_src, extra_rot_src, n_extra, channels, rows, rows, offsets, n_cols, n_cols,
+                       3.14159265358979323846 / 180.0, n_frames, scale, out_cols, n_out, pos_out, quat_out, stream);
 }
 
 #ifdef GMR_IK_STAMPS

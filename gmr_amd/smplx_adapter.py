@@ -13,7 +13,7 @@ tests pin it against a scipy restatement of the cited lines.
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -38,8 +38,10 @@ SMPLX_PARENTS: List[int] = [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13
 
 def get_smplx_data_offline_fast(global_orient, full_pose, joints, parents: Sequence[int] = SMPLX_PARENTS, src_fps: float = 30.0,
                                 tgt_fps: float = 30.0, joint_names: Sequence[str] = SMPLX_JOINT_NAMES,
-                                device: int = 0) -> Tuple[torch.Tensor, torch.Tensor, List[str], float]:
-    """-> (pos [T',J,3], quat [T',J,4] wxyz, joint names, aligned_fps); float64 CUDA tensors."""
+                                device: int = 0, columns: Optional[Sequence[str]] = None) -> Tuple[torch.Tensor, torch.Tensor, List[str], float]:
+    """-> (pos [T',J,3], quat [T',J,4] wxyz, joint names, aligned_fps); float64 CUDA tensors.
+    ``columns``: emit only these joints, in this order (e.g. ``ik_columns(config)``: the 14 an smplx_to_*.json config reads) --
+    their ancestors are chained inside the kernel, the rest of the 55 is neither read nor written."""
     lib = _native.load()
     dev = torch.device("cuda", device)
     as_t = lambda a: (a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a))).detach().to(dev, torch.float64)
@@ -61,12 +63,23 @@ def get_smplx_data_offline_fast(global_orient, full_pose, joints, parents: Seque
         aligned_fps = T_out / T * src_fps if T else tgt_fps  # :172
     else:
         T_out, resample, aligned_fps = T, 0, tgt_fps
-    pos = torch.empty((T_out, J, 3), dtype=torch.float64, device=dev)
-    quat = torch.empty((T_out, J, 4), dtype=torch.float64, device=dev)
+    names = list(joint_names[:J])
+    cols = None
+    if columns is not None:
+        sel = [str(c) for c in columns]
+        missing = [c for c in sel if c not in names]
+        if missing:
+            raise KeyError(missing[0])
+        cols = np.asarray([names.index(c) for c in sel], dtype=np.int32)
+        names = sel
+    B = len(names)
+    pos = torch.empty((T_out, B, 3), dtype=torch.float64, device=dev)
+    quat = torch.empty((T_out, B, 4), dtype=torch.float64, device=dev)
     vp = C.c_void_p
     if T_out > 0:
-        rc = lib.gmr_smplx_keypoints(parents.ctypes.data_as(vp), J, int(jt.shape[1]), vp(go.data_ptr()), vp(fp.data_ptr()), vp(jt.data_ptr()),
-                                     T, T_out, resample, vp(pos.data_ptr()), vp(quat.data_ptr()), vp(torch.cuda.current_stream(dev).cuda_stream))
+        rc = lib.gmr_smplx_keypoints_cols(parents.ctypes.data_as(vp), J, int(jt.shape[1]), vp(go.data_ptr()), vp(fp.data_ptr()), vp(jt.data_ptr()),
+                                          T, T_out, resample, cols.ctypes.data_as(vp) if cols is not None else None, B,
+                                          vp(pos.data_ptr()), vp(quat.data_ptr()), vp(torch.cuda.current_stream(dev).cuda_stream))
         if rc != 0:
-            raise RuntimeError(f"gmr_smplx_keypoints failed with status {rc}")
-    return pos, quat, list(joint_names[:J]), float(aligned_fps)
+            raise RuntimeError(f"gmr_smplx_keypoints_cols failed with status {rc}")
+    return pos, quat, names, float(aligned_fps)

@@ -317,3 +317,50 @@ def synth_clips_torch(cm: CompiledModel, lengths, seed: int, device, hard=False,
             quat[offs[c]:offs[c] + L] = hquat[j, :L].to(dtype)
         del hpos, hquat, tpos, tquat, qpos, q2
     return pos, quat, list(cm.slot_names), offs
+
+
+# ------------------------------------------------------------------ adapter workloads (rows f-1, f-2): LAFAN1-shaped BVH rows, AMASS-shaped SMPL-X arrays
+# The 22-bone LAFAN1 skeleton (bone names as bvh_to_g1.json reads them; offsets in cm, Y-up: a plausible human, not LAFAN1's data)
+LAFAN1_BONES: List[Tuple[str, int, Tuple[float, float, float]]] = [
+    ("Hips", -1, (0, 0, 0)), ("LeftUpLeg", 0, (10, -5, 0)), ("LeftLeg", 1, (0, -42, 0)), ("LeftFoot", 2, (0, -40, 0)), ("LeftToe", 3, (0, -6, 14)),
+    ("RightUpLeg", 0, (-10, -5, 0)), ("RightLeg", 5, (0, -42, 0)), ("RightFoot", 6, (0, -40, 0)), ("RightToe", 7, (0, -6, 14)),
+    ("Spine", 0, (0, 8, 0)), ("Spine1", 9, (0, 12, 0)), ("Spine2", 10, (0, 12, 0)), ("Neck", 11, (0, 22, 0)), ("Head", 12, (0, 10, 0)),
+    ("LeftShoulder", 11, (4, 18, 0)), ("LeftArm", 14, (14, 0, 0)), ("LeftForeArm", 15, (28, 0, 0)), ("LeftHand", 16, (25, 0, 0)),
+    ("RightShoulder", 11, (-4, 18, 0)), ("RightArm", 18, (-14, 0, 0)), ("RightForeArm", 19, (-28, 0, 0)), ("RightHand", 20, (-25, 0, 0))]
+
+
+def lafan_rows_torch(n_frames: int, device, seed: int = 0):
+    """3-channel motion rows [n_frames, 3 + 3 * 22] (root translation in cm, ZYX Euler angles in degrees) of a LAFAN1-shaped
+    skeleton, generated on the device: band-limited joint angles, a wandering root.  Returns (rows, parents, offsets, order)."""
+    import torch
+    g = torch.Generator(device=device).manual_seed(seed)
+    J = len(LAFAN1_BONES)
+    t = torch.arange(n_frames, dtype=torch.float64, device=device)[:, None] / 30.0
+    amp = torch.rand((1, 3 * J), generator=g, dtype=torch.float64, device=device) * 23.0 + 2.0
+    frq = torch.rand((1, 3 * J), generator=g, dtype=torch.float64, device=device) * 1.1 + 0.1
+    ph = torch.rand((1, 3 * J), generator=g, dtype=torch.float64, device=device) * 6.28
+    rows = torch.empty((n_frames, 3 + 3 * J), dtype=torch.float64, device=device)
+    rows[:, 3:] = amp * torch.sin(2 * np.pi * frq * t + ph)
+    rows[:, 4] += torch.rand((n_frames,), generator=g, dtype=torch.float64, device=device) * 360.0 - 180.0   # heading: any
+    rows[:, 0] = 100.0 * torch.sin(0.05 * t[:, 0])
+    rows[:, 1] = 92.0 + 2.0 * torch.sin(t[:, 0])
+    rows[:, 2] = 100.0 * torch.cos(0.031 * t[:, 0])
+    parents = np.array([p for _, p, _ in LAFAN1_BONES], dtype=np.int32)
+    offsets = np.array([o for _, _, o in LAFAN1_BONES], dtype=np.float64)
+    return rows, parents, offsets, (2, 1, 0)
+
+
+def smplx_arrays_torch(n_frames: int, device, n_joints: int = 55, joints_stride: int = 127, seed: int = 0):
+    """AMASS-shaped SMPL-X body-model outputs on the device: global_orient [T,3], full_pose [T,J,3] (axis-angle, smooth in time:
+    neighbouring mocap frames are a fraction of a degree apart), joints [T,joints_stride,3]."""
+    import torch
+    g = torch.Generator(device=device).manual_seed(seed)
+    t = torch.arange(n_frames, dtype=torch.float64, device=device)[:, None, None] / 120.0
+    base = torch.randn((1, n_joints, 3), generator=g, dtype=torch.float64, device=device) * 0.4
+    frq = torch.rand((1, n_joints, 3), generator=g, dtype=torch.float64, device=device) * 1.4 + 0.1
+    ph = torch.rand((1, n_joints, 3), generator=g, dtype=torch.float64, device=device) * 6.28
+    full_pose = base + 0.5 * torch.sin(2 * np.pi * frq * t + ph)
+    global_orient = full_pose[:, 0].contiguous()
+    joints = torch.randn((1, joints_stride, 3), generator=g, dtype=torch.float64, device=device) * 0.5 \
+        + 0.3 * torch.sin(2 * np.pi * 0.2 * t + torch.rand((1, joints_stride, 3), generator=g, dtype=torch.float64, device=device) * 6.28)
+    return global_orient, full_pose.contiguous(), joints.contiguous()

@@ -31,12 +31,12 @@
  *   gmr_fk             KinematicsModel.forward_kinematics (kinematics_model.py:213-246)
  *   gmr_fk_min_height  the clip-global `torch.min(body_pos[..., 2])` of the height adjust
  *                      (scripts/smplx_to_robot_dataset.py:118-126)
- *   gmr_smplx_keypoints the numeric part of get_smplx_data_offline_fast (general_motion_retargeting/utils/smpl.py:109-198)
+ *   gmr_smplx_keypoints, gmr_smplx_keypoints_cols  the numeric part of get_smplx_data_offline_fast (general_motion_retargeting/utils/smpl.py:109-198)
  *                      after the SMPL-X body model: slerp/lerp to the target frame rate, orientation chaining
  *   gmr_bvh_parse_header the HIERARCHY section of read_bvh (general_motion_retargeting/utils/lafan_vendor/extract.py:60-139)
  *   gmr_bvh_parse_motion the MOTION block of read_bvh (general_motion_retargeting/utils/lafan_vendor/extract.py:140-166): the
  *                      per-line regex + float() loop that dominates BVH loading in the reference
- *   gmr_bvh_fk         the numeric part of load_lafan1_file (general_motion_retargeting/utils/lafan1.py:8-40):
+ *   gmr_bvh_fk, gmr_bvh_fk_rows  the numeric part of load_lafan1_file (general_motion_retargeting/utils/lafan1.py:8-40):
  *                      euler_to_quat + quat_fk (utils/lafan_vendor/utils.py:56-103), Y-up -> Z-up, cm -> m,
  *                      LeftFootMod / RightFootMod synthesis
  */
@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define GMR_ABI_VERSION 3
+#define GMR_ABI_VERSION 4
 
 #define GMR_OK 0
 #define GMR_EINVAL (-1)    /* bad argument / blob / shape                     */
@@ -211,6 +211,15 @@ int gmr_smplx_keypoints(const int32_t *parents, int n_joints, int joints_stride,
                         const double *joints, int64_t n_frames, int64_t n_frames_out, int resample, double *pos_out, double *quat_out,
                         void *stream);
 
+/* The same with a column selection: out_cols host [n_out] names the joints to emit, column c of the outputs = joint out_cols[c]
+ * (each at most once); their ancestors are chained internally, joints that are neither emitted nor an ancestor of an emitted one are
+ * not read.  With the 14 joints an smplx_to_*.json config consumes, gmr_ik_solve reads a dense [n_frames_out][14][7] instead of
+ * picking 14 of 55 columns.  out_cols == NULL: all joints (n_out ignored).
+ *   pos_out device [n_frames_out][n_out][3], quat_out device [n_frames_out][n_out][4]                                        */
+int gmr_smplx_keypoints_cols(const int32_t *parents, int n_joints, int joints_stride, const double *global_orient, const double *full_pose,
+                             const double *joints, int64_t n_frames, int64_t n_frames_out, int resample, const int32_t *out_cols, int n_out,
+                             double *pos_out, double *quat_out, void *stream);
+
 /* Host-side parse of a BVH file's HIERARCHY section and MOTION header (stateless, no device involved; grammar and the
  * reference semantics it keeps are documented in gmr_amd/csrc/bvh_text.h).  Replaces the hierarchy loop of read_bvh
  * (general_motion_retargeting/utils/lafan_vendor/extract.py:60-139).
@@ -242,6 +251,21 @@ int64_t gmr_bvh_parse_motion(const char *text, size_t len, int64_t max_lines, do
 int gmr_bvh_fk(const int32_t *parents, int n_joints, const int32_t *euler_order, const int32_t *extra_pos_src,
                const int32_t *extra_rot_src, int n_extra, const double *local_pos, const double *euler_rad, int64_t n_frames,
                double scale, double *pos_out, double *quat_out, void *stream);
+
+/* The same fed with the file's own motion rows, as gmr_bvh_parse_motion wrote them (degrees, file units): the slicing of a row into
+ * root translation / per-joint channels (general_motion_retargeting/utils/lafan_vendor/extract.py:140-156) and the degrees -> radians
+ * step of load_lafan1_file (utils/lafan1.py:13) happen in the kernel, so nothing is reshaped or copied on the host.
+ *   channels   3: rows = 3 root position values + 3 angles per joint;  6: (position, angles) per joint;
+ *              9: 3 root position values + (position, angles, scale) per non-root joint, local position = offset + position * scale,
+ *                 zero root rotation
+ *   offsets    device [n_joints][3]  the joints' OFFSET lines (local positions where the rows carry none)
+ *   rows       device [n_frames][n_cols]
+ *   out_cols   host [n_out] or NULL: entries (joint j, or n_joints + k for extra k) to emit, column c = entry out_cols[c];
+ *              NULL = all n_joints + n_extra
+ *   pos_out    device [n_frames][n_out][3], quat_out device [n_frames][n_out][4]                                                  */
+int gmr_bvh_fk_rows(const int32_t *parents, int n_joints, const int32_t *euler_order, const int32_t *extra_pos_src,
+                    const int32_t *extra_rot_src, int n_extra, int channels, const double *offsets, const double *rows, int64_t n_cols,
+                    int64_t n_frames, double scale, const int32_t *out_cols, int n_out, double *pos_out, double *quat_out, void *stream);
 
 #ifdef __cplusplus
 }

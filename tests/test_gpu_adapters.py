@@ -1,0 +1,260 @@
+"""The two input-adapter kernels (rows f-1, f-2) beyond the reference-generated goldens of test_gpu_api.py: random skeletons of
+every lane layout (several frames per wavefront, one frame, two and three joints per lane), frame counts around the run and group
+edges, every row layout, column selections, the trigonometric arm of the slerp -- against numpy restatements of the formulas the
+kernels cite (Euler -> quaternion, hierarchy-order FK, Z-up turn; slerp / lerp / orientation chaining)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from gmr_amd import _native  # noqa: E402
+
+vp = C.c_void_p
+
+
+def _qmul(a, b):  # wxyz Hamilton product, broadcasting
+    w1, x1, y1, z1 = np.moveaxis(a, -1, 0)
+    w2, x2, y2, z2 = np.moveaxis(b, -1, 0)
+    return np.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                     w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], axis=-1)
+
+
+def _qrot(q, v):  # v + 2 w (u x v) + 2 u x (u x v)
+    u, w = q[..., 1:], q[..., :1]
+    t = 2.0 * np.cross(u, v)
+    return v + w * t + np.cross(u, t)
+
+
+def _axis_quat(ang, axis):
+    q = np.zeros(ang.shape + (4,))
+    q[..., 0] = np.cos(0.5 * ang)
+    q[..., 1 + axis] = np.sin(0.5 * ang)
+    return q
+
+
+def _bvh_restatement(parents, order, lpos, eul_rad, extra_pos, extra_rot, scale):
+    """lafan1.py:8-40 + lafan_vendor/utils.py:56-103 in numpy: Euler -> quaternion, FK in hierarchy order, Z-up, scale, extras."""
+    lq = _qmul(_axis_quat(eul_rad[..., 0], order[0]), _qmul(_axis_quat(eul_rad[..., 1], order[1]), _axis_quat(eul_rad[..., 2], order[2])))
+    T, J = lpos.shape[:2]
+    gq, gp = np.zeros((T, J, 4)), np.zeros((T, J, 3))
+    gq[:, 0], gp[:, 0] = lq[:, 0], lpos[:, 0]
+    for j in range(1, J):
+        p = parents[j]
+        gp[:, j] = _qrot(gq[:, p], lpos[:, j]) + gp[:, p]
+        gq[:, j] = _qmul(gq[:, p], lq[:, j])
+    rq = np.array([np.sqrt(0.5), np.sqrt(0.5), 0.0, 0.0])
+    gq = _qmul(np.broadcast_to(rq, gq.shape), gq)
+    gp = np.stack([gp[..., 0], -gp[..., 2], gp[..., 1]], axis=-1) * scale
+    if len(extra_pos):
+        gp = np.concatenate([gp, gp[:, extra_pos]], axis=1)
+        gq = np.concatenate([gq, gq[:, extra_rot]], axis=1)
+    return gp, gq
+
+
+def _random_tree(rng, J, chain_bias):
+    """parents in hierarchy order; chain_bias -> deep chains (many pointer-jumping rounds)."""
+    par = np.full(J, -1, dtype=np.int32)
+    for j in range(1, J):
+        par[j] = j - 1 if rng.random() < chain_bias else rng.integers(0, j)
+    return par
+
+
+def _rows_for(layout, lpos, eul_deg, offsets, scales=None):
+    T, J = lpos.shape[:2]
+    if layout == 3:
+        return np.concatenate([lpos[:, 0], eul_deg.reshape(T, -1)], axis=1)
+    if layout == 6:
+        return np.concatenate([lpos, eul_deg], axis=2).reshape(T, -1)
+    blk = np.concatenate([(lpos[:, 1:] - offsets[None, 1:]) / scales, eul_deg[:, 1:], scales], axis=2)  # 9: offset + position * scale
+    return np.concatenate([lpos[:, 0], blk.reshape(T, -1)], axis=1)
+
+
+def _call_rows(lib, dev, parents, order, extra_pos, extra_rot, layout, offsets, rows, scale, out_cols=None):
+    J, E, T = len(parents), len(extra_pos), rows.shape[0]
+    B = len(out_cols) if out_cols is not None else J + E
+    d_rows = torch.from_numpy(np.ascontiguousarray(rows)).to(dev)
+    d_off = torch.from_numpy(np.ascontiguousarray(offsets)).to(dev)
+    pos = torch.full((T, B, 3), float("nan"), dtype=torch.float64, device=dev)
+    quat = torch.full((T, B, 4), float("nan"), dtype=torch.float64, device=dev)
+    par, od = np.ascontiguousarray(parents, np.int32), np.asarray(order, np.int32)
+    ep, er = np.asarray(extra_pos, np.int32), np.asarray(extra_rot, np.int32)
+    oc = None if out_cols is None else np.asarray(out_cols, np.int32)
+    rc = lib.gmr_bvh_fk_rows(par.ctypes.data_as(vp), J, od.ctypes.data_as(vp), ep.ctypes.data_as(vp) if E else None, er.ctypes.data_as(vp) if E else None, E,
+                             layout, vp(d_off.data_ptr()), vp(d_rows.data_ptr()), rows.shape[1], T, scale,
+                             oc.ctypes.data_as(vp) if oc is not None else None, B, vp(pos.data_ptr()), vp(quat.data_ptr()), None)
+    torch.cuda.synchronize()
+    return rc, pos.cpu().numpy(), quat.cpu().numpy()
+
+
+@pytest.mark.parametrize("J,T,layout,bias", [(1, 7, 3, 0.5), (5, 130, 3, 0.9), (16, 257, 6, 0.3), (22, 1001, 3, 0.6), (31, 64, 9, 0.8), (32, 65, 3, 1.0),
+                                             (33, 200, 3, 0.5), (64, 129, 6, 1.0), (65, 130, 3, 0.7), (101, 250, 3, 0.6), (128, 33, 9, 0.95),
+                                             (129, 40, 3, 0.5), (192, 77, 6, 0.85)])
+def test_bvh_fk_rows_random_skeletons(J, T, layout, bias):
+    lib = _native.load()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(J * 1000 + T)
+    parents = _random_tree(rng, J, bias)
+    order = tuple(int(x) for x in rng.permutation(3))
+    offsets = rng.normal(0, 20.0, (J, 3))
+    lpos = np.repeat(offsets[None], T, axis=0)
+    lpos[:, 0] = np.cumsum(rng.normal(0, 2.0, (T, 3)), axis=0) + [0, 90, 0]
+    if layout != 3:
+        lpos[:, 1:] += rng.normal(0, 1.0, (T, J - 1, 3)) if J > 1 else 0.0
+    eul = rng.uniform(-180.0, 180.0, (T, J, 3)) * (rng.random((1, J, 1)) < 0.8) + rng.normal(0, 400.0, (T, J, 3)) * (rng.random((T, J, 1)) < 0.02)
+    scales = rng.uniform(0.5, 2.0, (T, max(J - 1, 0), 3))
+    if layout == 9:
+        if J < 2:
+            pytest.skip("9-channel rows need a non-root joint")
+        eul[:, 0] = 0.0   # the layout carries no root rotation
+    rows = _rows_for(layout, lpos, eul, offsets, scales)
+    if layout == 9:  # what the kernel reconstructs: offset + position * scale
+        blk = rows[:, 3:].reshape(T, J - 1, 9)
+        lpos = lpos.copy()
+        lpos[:, 1:] = offsets[None, 1:] + blk[:, :, 0:3] * blk[:, :, 6:9]
+    E = min(2, J)
+    extra_pos = [int(x) for x in rng.integers(0, J, E)]
+    extra_rot = [int(x) for x in rng.integers(0, J, E)]
+    rc, pos, quat = _call_rows(lib, dev, parents, order, extra_pos, extra_rot, layout, offsets, rows, 0.01)
+    assert rc == 0
+    p_ref, q_ref = _bvh_restatement(parents, order, lpos, np.radians(eul), extra_pos, extra_rot, 0.01)
+    scale_p = max(1.0, np.abs(p_ref).max())
+    assert np.abs(pos - p_ref).max() < 1e-11 * scale_p * max(1, J // 8)
+    assert np.abs(quat - q_ref).max() < 1e-12 * max(1, J // 4)   # unit quaternions; products of up to J of them
+    # a column selection is the same numbers in the requested columns, nothing else written
+    B = J + E
+    sel = [int(x) for x in rng.permutation(B)[: max(1, min(14, B))]]
+    rc, pos_s, quat_s = _call_rows(lib, dev, parents, order, extra_pos, extra_rot, layout, offsets, rows, 0.01, out_cols=sel)
+    assert rc == 0 and np.array_equal(pos_s, pos[:, sel]) and np.array_equal(quat_s, quat[:, sel])
+
+
+def test_bvh_fk_split_arrays_entry_equals_rows_entry():
+    """gmr_bvh_fk (ABI <= 3: local positions + radians as two arrays) runs the same kernel as gmr_bvh_fk_rows."""
+    lib = _native.load()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(3)
+    J, T = 22, 500
+    parents = _random_tree(rng, J, 0.6)
+    offsets = rng.normal(0, 20.0, (J, 3))
+    lpos = np.repeat(offsets[None], T, axis=0)
+    lpos[:, 0] = rng.normal(0, 50.0, (T, 3))
+    eul = rng.uniform(-180, 180, (T, J, 3))
+    rc, pos, quat = _call_rows(lib, dev, parents, (2, 1, 0), [3, 7], [4, 8], 3, offsets, _rows_for(3, lpos, eul, offsets), 0.01)
+    assert rc == 0
+    d_lp, d_er = torch.from_numpy(lpos).to(dev), torch.from_numpy(np.radians(eul)).to(dev)
+    p2 = torch.empty((T, J + 2, 3), dtype=torch.float64, device=dev)
+    q2 = torch.empty((T, J + 2, 4), dtype=torch.float64, device=dev)
+    od, ep, er = np.array([2, 1, 0], np.int32), np.array([3, 7], np.int32), np.array([4, 8], np.int32)
+    assert lib.gmr_bvh_fk(parents.ctypes.data_as(vp), J, od.ctypes.data_as(vp), ep.ctypes.data_as(vp), er.ctypes.data_as(vp), 2, vp(d_lp.data_ptr()),
+                          vp(d_er.data_ptr()), T, 0.01, vp(p2.data_ptr()), vp(q2.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(p2.cpu().numpy(), pos) and np.array_equal(q2.cpu().numpy(), quat)
+    # argument checks
+    bad = np.array([0, 5], np.int32)
+    assert lib.gmr_bvh_fk_rows(parents.ctypes.data_as(vp), J, od.ctypes.data_as(vp), None, None, 0, 3, vp(d_lp.data_ptr()), vp(d_lp.data_ptr()), 3 + 3 * J + 1, T, 0.01,
+                               None, 0, vp(p2.data_ptr()), vp(q2.data_ptr()), None) == -1                      # wrong row length
+    assert lib.gmr_bvh_fk_rows(parents.ctypes.data_as(vp), J, od.ctypes.data_as(vp), None, None, 0, 4, vp(d_lp.data_ptr()), vp(d_lp.data_ptr()), 3 + 3 * J, T, 0.01,
+                               None, 0, vp(p2.data_ptr()), vp(q2.data_ptr()), None) == -3                      # unknown layout
+    dup = np.array([1, 1], np.int32)
+    assert lib.gmr_bvh_fk_rows(parents.ctypes.data_as(vp), J, od.ctypes.data_as(vp), None, None, 0, 3, vp(d_lp.data_ptr()), vp(d_lp.data_ptr()), 3 + 3 * J, T, 0.01,
+                               dup.ctypes.data_as(vp), 2, vp(p2.data_ptr()), vp(q2.data_ptr()), None) == -1    # a column named twice
+    assert bad is not None
+
+
+def _smplx_restatement(go, fp, jt, parents, T_out, resample):
+    """smpl.py:75-107,127-196 in numpy (scipy for the rotation-vector conversions, as the reference)."""
+    from scipy.spatial.transform import Rotation as R
+    T, J = fp.shape[:2]
+    rv = fp.copy()
+    rv[:, 0] = go
+    pos = np.zeros((T_out, J, 3))
+    quat = np.zeros((T_out, J, 4))
+    tt = np.linspace(0, T - 1, T_out) if resample else np.arange(T, dtype=np.float64)
+    for k, t in enumerate(tt):
+        i1 = int(np.floor(t)); i2 = min(i1 + 1, T - 1); a = t - i1
+        q1 = R.from_rotvec(rv[i1]).as_quat()
+        if resample:
+            q2 = R.from_rotvec(rv[i2]).as_quat()
+            dot = np.sum(q1 * q2, axis=1)
+            q2 = np.where(dot[:, None] < 0, -q2, q2)
+            dot = np.abs(dot)
+            th0 = np.arccos(np.minimum(dot, 1.0))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                s1 = np.where(dot > 0.9995, a, np.sin(th0 * a) / np.sin(th0))
+                s0 = np.where(dot > 0.9995, 1 - a, np.cos(th0 * a) - dot * np.sin(th0 * a) / np.sin(th0))
+            q = s0[:, None] * q1 + s1[:, None] * q2
+            lq = R.from_rotvec(R.from_quat(q).as_rotvec())
+        else:
+            lq = R.from_rotvec(rv[i1])
+        rots = []
+        for i in range(J):
+            rots.append(lq[i] if i == 0 else rots[parents[i]] * lq[i])
+            quat[k, i] = rots[i].as_quat(scalar_first=True)
+        pos[k] = jt[i1, :J] + a * (jt[i2, :J] - jt[i1, :J])
+    return pos, quat
+
+
+@pytest.mark.parametrize("J,T,skip,big", [(55, 240, 4, False), (55, 241, 1, False), (55, 97, 2, True), (3, 50, 4, True), (24, 130, 1, False), (17, 129, 3, True),
+                                          (32, 64, 2, False), (33, 66, 4, True), (64, 40, 1, True)])
+def test_smplx_keypoints_random_trees(J, T, skip, big):
+    lib = _native.load()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(J * 100 + T)
+    parents = _random_tree(rng, J, 0.6)
+    base = rng.normal(0, 0.5, (1, J, 3))
+    fp = base + np.cumsum(rng.normal(0, 0.25 if big else 0.02, (T, J, 3)), axis=0)   # big: neighbouring frames far apart -> the trigonometric slerp arm
+    if J > 2:
+        fp[:, 2] = 0.0           # small-angle series of from_rotvec
+        fp[:, 1] *= 4.0          # rotation angles beyond pi: negative-w quaternions
+    go = fp[:, 0].copy()
+    S = J + 5
+    jt = np.cumsum(rng.normal(0, 0.01, (T, S, 3)), axis=0) + rng.normal(0, 0.5, (1, S, 3))
+    resample = skip > 1
+    T_out = T // skip if resample else T
+    d_go, d_fp, d_jt = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (go, fp, jt))
+
+    def call(cols):
+        B = J if cols is None else len(cols)
+        pos = torch.full((T_out, B, 3), float("nan"), dtype=torch.float64, device=dev)
+        quat = torch.full((T_out, B, 4), float("nan"), dtype=torch.float64, device=dev)
+        oc = None if cols is None else np.asarray(cols, np.int32)
+        rc = lib.gmr_smplx_keypoints_cols(parents.ctypes.data_as(vp), J, S, vp(d_go.data_ptr()), vp(d_fp.data_ptr()), vp(d_jt.data_ptr()), T, T_out, int(resample),
+                                          oc.ctypes.data_as(vp) if oc is not None else None, B, vp(pos.data_ptr()), vp(quat.data_ptr()), None)
+        torch.cuda.synchronize()
+        return rc, pos.cpu().numpy(), quat.cpu().numpy()
+
+    rc, pos, quat = call(None)
+    assert rc == 0
+    p_ref, q_ref = _smplx_restatement(go, fp, jt, parents, T_out, resample)
+    assert np.abs(pos - p_ref).max() < 1e-12
+    d = np.minimum(np.abs(quat - q_ref).max(-1), np.abs(quat + q_ref).max(-1))
+    assert d.max() < 1e-10, d.max()   # (the trigonometric arm divides by sin(theta_0) >= 0.03)
+    sel = [int(x) for x in rng.permutation(J)[: max(1, min(14, J))]]
+    rc, pos_s, quat_s = call(sel)
+    assert rc == 0 and np.array_equal(pos_s, pos[:, sel]) and np.array_equal(quat_s, quat[:, sel])
+
+
+def test_adapter_columns_feed_the_ik_directly(golden_dir):
+    """`columns=` of both adapters: the dense [T, 14, 7] the IK config consumes gives the same qpos as the full-width arrays."""
+    import os
+    from gmr_amd import GeneralMotionRetargeting as GMR
+    from gmr_amd.bvh import load_lafan1_file
+    from gmr_amd.smplx_adapter import SMPLX_PARENTS, get_smplx_data_offline_fast
+    g = GMR(src_human="bvh", tgt_robot="unitree_g1", actual_human_height=1.7)
+    path = os.path.join(golden_dir, "bvh_lafan_like.bvh")
+    full, sub = load_lafan1_file(path), load_lafan1_file(path, columns=g._cm.slot_names)
+    assert sub.body_names == list(g._cm.slot_names) and sub.pos.shape[1] == len(g._cm.slot_names) and abs(sub.human_height - full.human_height) < 1e-12
+    assert torch.equal(g.retarget_batch(full.pos, full.quat, full.body_names), g.retarget_batch(sub.pos, sub.quat, sub.body_names))
+    with pytest.raises(KeyError):
+        load_lafan1_file(path, columns=["Hips", "NoSuchBone"])
+    rng = np.random.default_rng(1)
+    T = 120
+    fp = rng.normal(0, 0.3, (1, 55, 3)) + np.cumsum(rng.normal(0, 0.02, (T, 55, 3)), axis=0)
+    jt = np.cumsum(rng.normal(0, 0.01, (T, 127, 3)), axis=0) + rng.normal(0, 0.5, (1, 127, 3))
+    g2 = GMR("smplx", "unitree_g1")
+    pf, qf, nf, _ = get_smplx_data_offline_fast(fp[:, 0], fp.reshape(T, -1), jt, SMPLX_PARENTS, src_fps=120.0)
+    ps, qs, ns, _ = get_smplx_data_offline_fast(fp[:, 0], fp.reshape(T, -1), jt, SMPLX_PARENTS, src_fps=120.0, columns=g2._cm.slot_names)
+    assert ns == list(g2._cm.slot_names) and ps.shape == (T // 4, 14, 3)
+    assert torch.equal(g2.retarget_batch(pf, qf, nf), g2.retarget_batch(ps, qs, ns))
