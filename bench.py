@@ -542,18 +542,39 @@ def main():
         # numpy in -> retarget_clips -> one pickle per clip on tmpfs; 256 clips
         import shutil
         import tempfile
-        npk = min(nd, 256)
-        hp_d, hq_d = pos[: npk * T].cpu().numpy(), quat[: npk * T].cpu().numpy()
+        # batches of one clip per wavefront slot (2048): batch k + 1 is solved while the writer threads put batch k on tmpfs.
+        # Host key-points = the 14 columns the IK config consumes (what the adapters' `columns=` deliver), float32
+        per = min(S, 2048)
+        nbat = max(1, min(S, 8192) // per)
+        npk = per * nbat
+        sc_t = torch.from_numpy(np.asarray(sc, dtype=np.int64)).to(dev)
+        hp_d, hq_d = pos[: npk * T].index_select(1, sc_t).cpu().numpy(), quat[: npk * T].index_select(1, sc_t).cpu().numpy()
+        names_d = [names[i] for i in sc]
         tmpd = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        workers = max(2, min(16, host_cores()))
 
         def to_pickles():
-            motions = dataset.retarget_clips(gmr, hp_d, hq_d, names, offs[: npk + 1])
+            with dataset.MotionWriter(workers=workers, override=True) as w:
+                for b in range(nbat):
+                    motions = dataset.retarget_clips(gmr, hp_d[b * per * T:(b + 1) * per * T], hq_d[b * per * T:(b + 1) * per * T], names_d, offs[: per + 1])
+                    w.submit(motions, [os.path.join(tmpd, f"{b * per + i}.pkl") for i in range(per)])
+        t_pk, _ = timed(to_pickles, reps=3)
+
+        pers = min(per, 512)
+
+        def to_pickles_serial():  # round 2's form on 512 clips: one batch, then one pickle.dump after the other
+            motions = dataset.retarget_clips(gmr, hp_d[: pers * T], hq_d[: pers * T], names_d, offs[: pers + 1])
             for i, mo in enumerate(motions):
-                dataset.save_motion(os.path.join(tmpd, f"{i}.pkl"), mo, override=True)
-        t_pk, _ = timed(to_pickles, reps=2)
+                with open(os.path.join(tmpd, f"s{i}.pkl"), "wb") as f:
+                    pickle.dump(mo, f)
+        import pickle
+        t_pks, _ = timed(to_pickles_serial, reps=2)
+        same_bytes = all(open(os.path.join(tmpd, f"s{i}.pkl"), "rb").read() == open(os.path.join(tmpd, f"{i}.pkl"), "rb").read() for i in range(0, pers, max(1, pers // 8)))
         shutil.rmtree(tmpd, ignore_errors=True)
         result["dataset_path"] = {"clips": nd, "frames": nd * T, "frames_per_s_device": nd * T / t_dev, "frames_per_s_to_host": nd * T / t_all,
-                                  "frames_per_s_host_keypoints_to_pickles": npk * T / t_pk, "pickle_clips": npk,
+                                  "frames_per_s_host_keypoints_to_pickles": npk * T / t_pk, "pickle_clips": npk, "pickle_batches": nbat, "writer_threads": workers,
+                                  "frames_per_s_host_keypoints_to_pickles_serial": pers * T / t_pks, "pickles_byte_identical_to_serial": bool(same_bytes),
+                                  "pickle_bytes_per_frame": 24 + 32 + (eng.nq - 7) * 8 + eng.nbody * 12,
                                   "includes": "ik_kernel + fk_kernel (local_body_pos) + fk min-height + root adjustments; `to_host` adds the D2H of "
                                               "root_pos / root_rot / dof_pos (f64) + local_body_pos (f32, 456 B/frame) into pinned host arrays and the per-clip dicts"}
         # BASELINE config 2 taken literally: ONE 3000-frame clip on one GPU, parallel-in-time chunks with verified
@@ -701,7 +722,7 @@ def adapters_leg(dev, bvh_frames=4_000_000, smplx_frames_out=1_000_000, steps=3,
                                      vp(pos.data_ptr()), vp(quat.data_ptr()), st)
             assert rc == 0, rc
         ms = timed(run)
-        out.setdefault("bvh", {})[label] = record("gmr::bvh_fk_kernel<1>", bvh_frames, ms, (3 + 3 * J) * 8, B * 56,
+        out.setdefault("bvh", {})[label] = record("gmr::bvh_fk_kernel<1, false>", bvh_frames, ms, (3 + 3 * J) * 8, B * 56,
                                                   f"LAFAN1-shaped: 22 joints, 3-channel rows in degrees, {B} output columns x (3 + 4) float64")
         del pos, quat
     del rows

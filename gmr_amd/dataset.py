@@ -88,17 +88,202 @@ def retarget_clips(gmr: GeneralMotionRetargeting, pos, quat, body_names: Sequenc
     return motions_from_qpos(gmr, qpos, seq_offsets, fps, height_adjust=height_adjust, root_origin_offset=root_origin_offset)
 
 
+# ------------------------------------------------------------------ writing motion files (row f-3)
+class _RawBytes:
+    """The data of a C-contiguous array standing in for the ``bytes`` object numpy's reduce would copy it into."""
+    __slots__ = ("view",)
+
+    def __init__(self, arr: np.ndarray):
+        self.view = memoryview(arr).cast("B")
+
+    def __len__(self):
+        return self.view.nbytes
+
+
+class _MotionPickler(pickle._Pickler):
+    """``pickle.dump(motion, f)`` byte for byte (protocol 4, the default the reference's ``pickle.dump`` uses,
+    scripts/smplx_to_robot_dataset.py:143-146), without the two things that make it slow for motion dicts: ``ndarray.__reduce__``
+    first copies every array into a ``bytes`` object (under the GIL), and only then is that copy written.  Here an array's reduce
+    tuple is rebuilt around a view of its own memory and the payload goes from that memory straight into ``file.write`` (which
+    releases the GIL), so a pool of threads writes clips in parallel.  ``fast_pickle_ok()`` checks the byte identity once per
+    process against the stock pickler; where it does not hold the stock pickler is used."""
+
+    def reducer_override(self, obj):
+        if type(obj) is np.ndarray and obj.flags.c_contiguous and obj.dtype.kind in "fiub" and obj.nbytes >= 1 << 16:
+            fn, args, state = np.empty((0,) * obj.ndim, dtype=obj.dtype).__reduce__()
+            return fn, args, (state[0], obj.shape, obj.dtype, False, _RawBytes(obj))
+        return NotImplemented
+
+    def _save_raw(self, obj):  # pickle._Pickler.save_bytes for a payload that is a view, not a bytes object
+        n = len(obj)
+        if n > 0xFFFFFFFF:
+            self._write_large_bytes(pickle.BINBYTES8 + n.to_bytes(8, "little"), obj.view)
+        else:
+            self._write_large_bytes(pickle.BINBYTES + n.to_bytes(4, "little"), obj.view)
+        self.memoize(obj)
+
+    dispatch = dict(pickle._Pickler.dispatch)
+    dispatch[_RawBytes] = _save_raw
+
+
+_FAST_PICKLE_OK: Optional[bool] = None
+
+
+def fast_pickle_ok() -> bool:
+    """True when ``_MotionPickler`` reproduces the stock ``pickle.dump`` byte for byte on a motion-shaped dict here (checked once:
+    it rests on numpy's reduce format and the pickler's framing rules, both of which a new version could change)."""
+    global _FAST_PICKLE_OK
+    if _FAST_PICKLE_OK is None:
+        import io
+        rng = np.random.default_rng(0)
+        probe = {"fps": 30, "root_pos": rng.random((4000, 3)), "root_rot": rng.random((4000, 4)), "dof_pos": rng.random((4000, 29)),
+                 "local_body_pos": rng.random((4000, 38, 3)).astype(np.float32), "link_body_list": ["a", "b"], "small": rng.random((5, 3))}
+        f = io.BytesIO()
+        try:
+            _MotionPickler(f, pickle.DEFAULT_PROTOCOL).dump(probe)
+            _FAST_PICKLE_OK = pickle.DEFAULT_PROTOCOL >= 4 and f.getvalue() == pickle.dumps(probe)
+        except Exception:
+            _FAST_PICKLE_OK = False
+    return _FAST_PICKLE_OK
+
+
 def save_motion(path: str, motion: Dict, override: bool = False) -> bool:
-    """Pickle one motion dict; like the scripts, skip files that already exist unless ``override`` (:219)."""
+    """Pickle one motion dict; like the scripts, skip files that already exist unless ``override`` (:219).  The file is
+    what ``pickle.dump(motion, f)`` writes, byte for byte (see ``_MotionPickler``)."""
     if os.path.exists(path) and not override:
         return False
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     if str(path).endswith(".pt"):  # the torch twin of the schema (scripts/convert_motion_pkl_to_pt.py:40-48): arrays as tensors
         torch.save({k: torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v for k, v in motion.items()}, path)
         return True
-    with open(path, "wb") as f:
-        pickle.dump(motion, f)
+    if fast_pickle_ok():
+        _write_all(path, motion_stream(motion))
+    else:
+        with open(path, "wb") as f:
+            pickle.dump(motion, f)
     return True
+
+
+class _Pieces:
+    """File object of ``_MotionPickler`` that keeps what it is given: small pieces as bytes, array payloads as views."""
+
+    def __init__(self):
+        self.pieces = []
+
+    def write(self, b):
+        self.pieces.append(b if isinstance(b, memoryview) and b.nbytes >= 1 << 16 else bytes(b))
+        return len(b)
+
+
+_STREAM_TEMPLATES: Dict = {}
+
+
+def motion_stream(motion: Dict) -> list:
+    """The pickle of a motion dict as a list of buffers (headers as bytes, array payloads as views of the arrays' own memory).
+    Clips of one batch differ in their numbers only, so the header pieces are kept per layout -- keys, array shapes and dtypes,
+    and the pickle of everything that is not a large array -- and a clip of a known layout costs a dict lookup, not a pickler run."""
+    big = [(k, v) for k, v in motion.items() if type(v) is np.ndarray and v.flags.c_contiguous and v.dtype.kind in "fiub" and v.nbytes >= 1 << 16]
+    big_keys = {k for k, _ in big}
+    key = (tuple(motion.keys()), tuple((k, v.shape, v.dtype.str) for k, v in big),
+           pickle.dumps([v for k, v in motion.items() if k not in big_keys], pickle.DEFAULT_PROTOCOL))
+    tmpl = _STREAM_TEMPLATES.get(key)
+    if tmpl is None:
+        out = _Pieces()
+        _MotionPickler(out, pickle.DEFAULT_PROTOCOL).dump(motion)
+        views = [id(p.obj) if isinstance(p, memoryview) else None for p in out.pieces]
+        order = {id(v): k for k, v in big}
+        # payload pieces are views whose exporter is one of the large arrays: remember which key goes where
+        tmpl = [order[i] if i in order else p for p, i in zip(out.pieces, views)]
+        if sum(isinstance(t, str) for t in tmpl) == len(big) and all(not isinstance(t, memoryview) for t in tmpl):
+            if len(_STREAM_TEMPLATES) >= 256:
+                _STREAM_TEMPLATES.clear()
+            _STREAM_TEMPLATES[key] = tmpl
+        return out.pieces
+    return [memoryview(motion[t]).cast("B") if isinstance(t, str) else t for t in tmpl]
+
+
+def _write_all(path: str, pieces: list) -> None:
+    """One gather-write of the whole file: a single system call, which is also the single stretch a writer thread spends without
+    the GIL (threads that re-take the GIL between several writes of one file queue up behind each other's Python code)."""
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o666)
+    try:
+        views = [memoryview(p).cast("B") for p in pieces]
+        while views:
+            n = os.writev(fd, views[:1024])
+            while n > 0 and views:  # (a short write: drop what went out, go on with the rest)
+                if n >= views[0].nbytes:
+                    n -= views[0].nbytes
+                    views.pop(0)
+                else:
+                    views[0] = views[0][n:]
+                    n = 0
+            while views and views[0].nbytes == 0:
+                views.pop(0)
+    finally:
+        os.close(fd)
+
+
+class MotionWriter:
+    """Writes motion files on a pool of threads while the caller goes on to the next batch (the reference writes each clip from
+    the process that solved it, scripts/smplx_to_robot_dataset.py:134-146, 241-242: one pickle per clip, skipped when it exists).
+
+        with MotionWriter(workers=8) as w:
+            for batch in batches:                        # batch k + 1 is solved while batch k is being written
+                motions = retarget_clips(gmr, ...)
+                w.submit(motions, paths)
+        w.written, w.skipped
+
+    ``submit`` returns at once; the motion dicts (row slices of the batch's pinned result arrays, ``motions_from_qpos``) stay
+    alive until their files are closed.  An error in a worker is raised by the next ``submit`` / ``close``."""
+
+    def __init__(self, workers: int = 8, override: bool = False):
+        from concurrent.futures import ThreadPoolExecutor
+        self._pool = ThreadPoolExecutor(max_workers=max(1, int(workers)))
+        self._override = override
+        self._futures = []
+        self.written = 0
+        self.skipped = 0
+        fast_pickle_ok()  # (decide once, before the threads start)
+
+    def _reap(self, wait: bool):
+        keep = []
+        for f in self._futures:
+            if wait or f.done():
+                if f.result():
+                    self.written += 1
+                else:
+                    self.skipped += 1
+            else:
+                keep.append(f)
+        self._futures = keep
+
+    def submit(self, motions: Sequence[Dict], paths: Sequence[str]) -> None:
+        if len(motions) != len(paths):
+            raise ValueError("one path per motion")
+        self._reap(False)
+        for m, p in zip(motions, paths):
+            self._futures.append(self._pool.submit(save_motion, p, m, self._override))
+
+    def close(self) -> None:
+        try:
+            self._reap(True)
+        finally:
+            self._pool.shutdown(wait=True)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+
+def save_motions(motions: Sequence[Dict], paths: Sequence[str], workers: int = 8, override: bool = False) -> int:
+    """Write a batch of motion files (``.pkl`` or ``.pt`` by extension) on ``workers`` threads; returns how many were written
+    (existing files are skipped unless ``override``).  Files are byte-identical to those of a serial ``save_motion`` loop."""
+    with MotionWriter(workers, override) as w:
+        w.submit(motions, paths)
+    return w.written
 
 
 def load_robot_motion(motion_file: str):

@@ -388,3 +388,50 @@ def test_motion_files_pickle_and_torch_twin(tmp_path):
         assert fps == 30 and names == ["pelvis", "torso"] and lb.dtype == np.float32 and rp.dtype == np.float64
         assert np.array_equal(rp, m["root_pos"]) and np.array_equal(rr_wxyz, m["root_rot"][:, [3, 0, 1, 2]]) and np.array_equal(dp, m["dof_pos"])
         assert np.array_equal(lb, m["local_body_pos"]) and set(d) == set(m)
+
+
+def test_motion_writer_pool_is_byte_identical_to_serial_pickle(tmp_path):
+    """dataset.save_motions / MotionWriter (row f-3: the overlapped batched writer): every file equals what the reference's
+    ``pickle.dump(motion, f)`` (scripts/smplx_to_robot_dataset.py:143-146) writes for the same dict, byte for byte -- clips that are
+    row slices of one batch array, arrays below and above the pickler's 64 KiB framing threshold, an empty clip, a fps given as a
+    float --; existing files are skipped unless override; .pt files equal the serial torch.save; load_robot_motion round-trips."""
+    import pickle
+    from gmr_amd import dataset
+    assert dataset.fast_pickle_ok()
+    rng = np.random.default_rng(3)
+    lens = [4000, 1, 0, 2731, 90, 300]
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    N = int(offs[-1])
+    big = [rng.random((N, 3)), rng.random((N, 4)), rng.random((N, 29)), rng.random((N, 38, 3)).astype(np.float32)]
+    big[1] /= np.linalg.norm(big[1], axis=1, keepdims=True)
+    names = [f"body{i}" for i in range(38)]
+    motions = [{"fps": 30 if s % 2 else 29.97, "root_pos": big[0][a:b], "root_rot": big[1][a:b], "dof_pos": big[2][a:b], "local_body_pos": big[3][a:b],
+                "link_body_list": names} for s, (a, b) in enumerate(zip(offs[:-1], offs[1:]))]
+    paths = [str(tmp_path / "out" / f"c{s}.pkl") for s in range(len(lens))]
+    assert dataset.save_motions(motions, paths, workers=4) == len(lens)
+    for m, p in zip(motions, paths):
+        assert open(p, "rb").read() == pickle.dumps(m)
+        d, fps, rp, rr_wxyz, dp, lb, nm = dataset.load_robot_motion(p)
+        assert fps == m["fps"] and np.array_equal(rp, m["root_pos"]) and np.array_equal(lb, m["local_body_pos"]) and nm == names
+        dataset.validate_motion(d, nq=36) if len(rp) else None
+    # skip-if-exists (scripts/smplx_to_robot_dataset.py:219), counted; override rewrites
+    open(paths[1], "wb").write(b"x")
+    with dataset.MotionWriter(workers=2) as w:
+        w.submit(motions, paths)
+    assert (w.written, w.skipped) == (0, len(lens)) and open(paths[1], "rb").read() == b"x"
+    assert dataset.save_motions(motions[:2], paths[:2], workers=2, override=True) == 2 and open(paths[1], "rb").read() == pickle.dumps(motions[1])
+    # the torch twin through the pool == torch.save called serially
+    import torch
+    pt = [str(tmp_path / f"c{s}.pt") for s in range(2)]
+    assert dataset.save_motions(motions[:2], pt, workers=2) == 2
+    os.makedirs(tmp_path / "serial")
+    for s, (m, p) in enumerate(zip(motions, pt)):
+        ref = str(tmp_path / "serial" / f"c{s}.pt")  # (the archive carries the file's stem)
+        torch.save({k: torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v for k, v in m.items()}, ref)
+        assert open(p, "rb").read() == open(ref, "rb").read()
+        assert np.array_equal(dataset.load_robot_motion(p)[4], m["dof_pos"])
+    # a worker's error surfaces
+    with pytest.raises(Exception):
+        dataset.save_motions([{"fps": 30, "bad": (lambda: 0)}], [str(tmp_path / "bad.pkl")], workers=1)
+    with pytest.raises(ValueError):
+        dataset.save_motions(motions, paths[:2])
