@@ -611,6 +611,16 @@ def main():
                     "verified_chunked_frames_per_s": nfr / t_rt, "resolved_frames": info_rt["resolved_frames"],
                     "note": "NOT the reference's semantics: every clip starts with the base on its first root target instead of qpos0"}
             del lc
+        # BASELINE config 3 from FILES (scripts/bvh_to_robot_dataset.py:59-104 end to end): a folder of 24 BVH files x 4000 frames on
+        # tmpfs -> qpos; MOTION blocks parsed on the device, batches read ahead, verified chunks (tools/config3_files_bench.py)
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import config3_files_bench
+            ff = config3_files_bench.run(24, 4000, max(2, min(16, host_cores())), dev.index)
+            result["long_clips"]["from_files"] = {"files": ff["files"], "frames": ff["frames"], "text_MB": ff["keypoint_text_MB"], **ff["from_files"],
+                                                  "loader_only": {"text_MB": ff["text_MB"], **ff["loader"]}}
+        except Exception as ex:
+            result["long_clips"]["from_files"] = {"error": repr(ex)}
         # BASELINE config 4: five robots' batches (5 x 64 clips x 1000 frames) as ONE launch (gmr_group_*) and as five launches on
         # five streams (round 1's form)
         try:

@@ -17,7 +17,8 @@ only flips signs; every consumer is sign-insensitive).
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List, Tuple
+import os
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -72,14 +73,22 @@ class BvhAnim:
         return rotations
 
 
-def _parse_motion(block: bytes, fnum: int, max_cols: int, filename: str) -> np.ndarray:
+def _buf(raw):
+    """(pointer argument, length) of a bytes object or a uint8 numpy array."""
+    if isinstance(raw, np.ndarray):
+        return C.c_void_p(raw.ctypes.data), int(raw.nbytes)
+    return raw, len(raw)
+
+
+def _parse_motion(block, fnum: int, max_cols: int, filename: str) -> np.ndarray:
     """The first ``fnum`` non-empty lines of the motion block as a float64 ``[fnum, columns]`` array (native parser).
     ``max_cols`` bounds the row length (the hierarchy fixes it); longer rows are reported as malformed."""
     lib = _native.load()
     cap = fnum * max_cols + 1
     out = np.empty(cap, dtype=np.float64)
     n_lines, n_cols = C.c_int64(0), C.c_int64(0)
-    n = lib.gmr_bvh_parse_motion(block, len(block), fnum, out.ctypes.data, cap, C.byref(n_lines), C.byref(n_cols))
+    ptr, nbytes = _buf(block)
+    n = lib.gmr_bvh_parse_motion(ptr, nbytes, fnum, out.ctypes.data, cap, C.byref(n_lines), C.byref(n_cols))
     if n < 0:
         raise ValueError(f"{filename}: malformed motion block (bad number or ragged rows)")
     if n_lines.value < fnum:
@@ -87,7 +96,7 @@ def _parse_motion(block: bytes, fnum: int, max_cols: int, filename: str) -> np.n
     return out[:n].reshape(fnum, n_cols.value)
 
 
-def _parse_header(raw: bytes, filename: str):
+def _parse_header(raw, filename: str):
     """HIERARCHY section + MOTION header through the library's tokenizer (``gmr_bvh_parse_header``, grammar in
     gmr_amd/csrc/bvh_text.h).  Returns (names, parents, offsets, channels per joint, euler order, n_frames, frame time, motion offset)."""
     lib = _native.load()
@@ -100,7 +109,8 @@ def _parse_header(raw: bytes, filename: str):
         channels = np.empty(max_j, dtype=np.int32)
         order = np.empty(3, dtype=np.int32)
         fnum, ftime, moff = C.c_int64(0), C.c_double(0.0), C.c_size_t(0)
-        n = lib.gmr_bvh_parse_header(raw, len(raw), max_j, names_buf, len(names_buf), parents.ctypes.data_as(vp), offsets.ctypes.data_as(vp),
+        ptr, nbytes = _buf(raw)
+        n = lib.gmr_bvh_parse_header(ptr, nbytes, max_j, names_buf, len(names_buf), parents.ctypes.data_as(vp), offsets.ctypes.data_as(vp),
                                      channels.ctypes.data_as(vp), order.ctypes.data_as(vp), C.byref(fnum), C.byref(ftime), C.byref(moff))
         if n == -2 and max_j < (1 << 16):
             max_j *= 4
@@ -112,23 +122,30 @@ def _parse_header(raw: bytes, filename: str):
                 tuple(int(x) for x in order), int(fnum.value), float(ftime.value), int(moff.value))
 
 
-def read_bvh(filename: str) -> BvhAnim:
-    with open(filename, "rb") as f:
-        raw = f.read()
-    names, parents, offsets, chan, order, fnum, frametime, moff = _parse_header(raw, filename)
-    motion_block = raw[moff:]
+def _layout(names, chan, filename: str):
+    """Row layout of a parsed hierarchy: (channels, numbers per row); rejects what the loader cannot lay out."""
     channels = int(chan[-1])  # the reference shapes the motion rows by the LAST joint's channel count (extract.py:104-106)
     if (channels == 3 and (chan[0] not in (3, 6) or np.any(chan[1:] != 3))) or (channels == 6 and np.any(chan != 6)) \
             or (channels == 9 and (chan[0] != 3 or np.any(chan[1:] != 9))):
         raise NotImplementedError(f"{filename}: joints with mixed channel counts are not supported")
     J = len(names)
-    data = _parse_motion(motion_block, fnum, 9 * J + 3, filename)  # the ctypes call releases the GIL: files parse in parallel threads
     if channels == 3 and chan[0] == 3:  # a root without translation channels: the reference reads its first three columns as one anyway
         raise NotImplementedError(f"{filename}: a 3-channel root is not supported")
     if channels not in (3, 6, 9):
         raise NotImplementedError(f"{filename}: {channels}-channel joints are not supported")
-    want = {3: 3 + 3 * J, 6: 6 * J, 9: 3 + 9 * (J - 1)}[channels]
-    if (channels == 9 and J < 2) or data.shape[1] != want:
+    if channels == 9 and J < 2:
+        raise ValueError(f"{filename}: a 9-channel file needs a non-root joint")
+    return channels, {3: 3 + 3 * J, 6: 6 * J, 9: 3 + 9 * (J - 1)}[channels]
+
+
+def read_bvh(filename: str) -> BvhAnim:
+    with open(filename, "rb") as f:
+        raw = f.read()
+    names, parents, offsets, chan, order, fnum, frametime, moff = _parse_header(raw, filename)
+    channels, want = _layout(names, chan, filename)
+    J = len(names)
+    data = _parse_motion(raw[moff:], fnum, 9 * J + 3, filename)  # the ctypes call releases the GIL: files parse in parallel threads
+    if data.shape[1] != want:
         raise ValueError(f"{filename}: expected {want} columns, found {data.shape[1]}")
     return BvhAnim(names, np.asarray(parents, dtype=np.int32), np.asarray(offsets, dtype=np.float64), order, data, channels, frametime)
 
@@ -272,29 +289,186 @@ def _check_one_skeleton(files, anims):
             raise ValueError(f"{f}: skeleton differs from {files[0]} (one batch = one skeleton)")
 
 
-def load_lafan1_files(bvh_files, device: int = 0, threads: int = 8, columns=None) -> BvhBatch:
-    """A folder's worth of BVH files -> one GPU batch (the file loop of scripts/bvh_to_robot_dataset.py:59-80, where every file
-    is parsed with regexes and turned into per-frame dicts one after the other).  The text of the files is parsed on ``threads``
-    host threads (both native parsers release the GIL) straight into one pinned row array, and ONE ``gmr_bvh_fk_rows`` launch does
-    row slicing, degrees -> radians, Euler -> quaternion, the skeleton FK, Y-up -> Z-up, cm -> m and the FootMod synthesis for all
-    of them.  All files must share one skeleton (names, parents, offsets, Euler order, channel layout), as a dataset does; the
-    height estimate of every clip (lafan1.py:45-69, from its own last frame) comes back with the batch."""
+class _FileText:
+    """What the host keeps of a batch of files whose MOTION blocks are parsed on the device: the files' bytes in ONE page-locked
+    array (read straight into it) and each file's parsed header."""
+
+    def __init__(self, files, buf, starts, sizes, heads):
+        self.files, self.buf, self.starts, self.sizes, self.heads = files, buf, starts, sizes, heads
+
+    def anim0(self) -> BvhAnim:
+        names, parents, offsets, chan, order, fnum, frametime, moff = self.heads[0]
+        channels, ncol = _layout(names, chan, self.files[0])
+        return BvhAnim(names, np.asarray(parents, dtype=np.int32), np.asarray(offsets, dtype=np.float64), order, np.zeros((0, ncol)), channels, frametime)
+
+
+_PINNED_TEXT: Dict[int, torch.Tensor] = {}
+
+
+def _pinned_bytes(n: int, slot: int) -> torch.Tensor:
+    """A grow-only page-locked byte buffer per slot (two slots alternate when batches are read ahead): page-locking is what a
+    fresh pinned allocation costs, so it is paid once per process, not once per batch."""
+    t = _PINNED_TEXT.get(slot)
+    if t is None or t.numel() < n:
+        t = torch.empty(max(n, 1 << 20) * 5 // 4, dtype=torch.uint8, pin_memory=True)
+        _PINNED_TEXT[slot] = t
+    return t
+
+
+def _read_files(files: List[str], threads: int, slot: int = 0) -> _FileText:
+    """Read the files into one pinned byte array (``readinto``: no intermediate bytes objects) and parse their HIERARCHY sections,
+    on ``threads`` host threads (file reads and the native header parser release the GIL)."""
     from concurrent.futures import ThreadPoolExecutor
+    sizes = np.array([os.path.getsize(f) for f in files], dtype=np.int64)
+    starts = np.concatenate([[0], np.cumsum((sizes + 63) // 64 * 64)]).astype(np.int64)  # every file on a 64-byte boundary
+    buf = _pinned_bytes(int(starts[-1]) + 64, slot)
+    host = buf.numpy()
+
+    def one(k):
+        a, n = int(starts[k]), int(sizes[k])
+        view = host[a:a + n]
+        with open(files[k], "rb", buffering=0) as f:
+            got = 0
+            while got < n:
+                r = f.readinto(memoryview(view)[got:])
+                if not r:
+                    raise ValueError(f"{files[k]}: file shrank while it was read")
+                got += r
+        return _parse_header(view, files[k])
+
+    with ThreadPoolExecutor(max_workers=max(1, min(threads, len(files)))) as ex:
+        heads = list(ex.map(one, range(len(files))))
+    return _FileText(files, buf, starts, sizes, heads)
+
+
+def _rows_on_device(ft: _FileText, dev: torch.device, stats: Optional[dict] = None):
+    """The batch's MOTION blocks -> ``rows [N, ncol]`` float64 on the device (``gmr_bvh_parse_motion_device``): one H2D copy of the
+    files as they are, three launches.  Tokens off the exact fast path are parsed by the host parser and patched in; a file whose
+    structure the device rejects goes through the host parser whole (which raises what it always raised).  Returns (a0, rows, offs)."""
+    lib = _native.load()
+    files, heads = ft.files, ft.heads
+    a0 = ft.anim0()
+    ncol = int(a0.rows.shape[1])
+    for f, h in zip(files, heads):
+        names, parents, offsets, chan, order, fnum, frametime, moff = h
+        ch, nc = _layout(names, chan, f)
+        if names != a0.bones or not np.array_equal(parents, a0.parents) or tuple(order) != tuple(a0.order) or ch != a0.channels \
+                or not np.array_equal(np.asarray(offsets, dtype=np.float64), a0.offsets):
+            raise ValueError(f"{f}: skeleton differs from {files[0]} (one batch = one skeleton)")
+    lens = np.array([h[5] for h in heads], dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    N, nf = int(offs[-1]), len(files)
+    total = int(ft.starts[-1])
+    text = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
+    text[:total].copy_(ft.buf[:total], non_blocking=True)
+    rows = torch.empty((N, ncol), dtype=torch.float64, device=dev)
+    seg_b = (ft.starts[:-1] + np.array([h[7] for h in heads], dtype=np.int64)).astype(np.int64)
+    seg_e = (ft.starts[:-1] + ft.sizes).astype(np.int64)
+    status = np.zeros(nf, dtype=np.int32)
+    ntok = np.zeros(nf, dtype=np.int64)
+    max_slow = 1 << 16
+    slow = np.zeros((max_slow, 3), dtype=np.int64)
+    n_slow = C.c_int64(0)
+    vp = C.c_void_p
+    row_b = np.ascontiguousarray(offs[:-1])
+    rc = lib.gmr_bvh_parse_motion_device(vp(text.data_ptr()), total, nf, seg_b.ctypes.data_as(vp), seg_e.ctypes.data_as(vp), lens.ctypes.data_as(vp), ncol,
+                                         row_b.ctypes.data_as(vp), vp(rows.data_ptr()), status.ctypes.data_as(vp), ntok.ctypes.data_as(vp),
+                                         slow.ctypes.data_as(vp), max_slow, C.byref(n_slow), vp(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"gmr_bvh_parse_motion_device failed with status {rc}")
+    host = ft.buf.numpy()
+    redo = set(int(k) for k in np.nonzero(status)[0])
+    ns = int(n_slow.value)
+    if ns > max_slow:
+        redo |= set(range(nf))
+    elif ns > 0:
+        # tokens off the fast path: the host parser's slow path (strtod) on each, patched into the rows
+        idx, val = [], []
+        out1 = np.empty(2, dtype=np.float64)
+        nl, nc = C.c_int64(0), C.c_int64(0)
+        for k, t, b in slow[:ns]:
+            if int(k) in redo:
+                continue
+            e = int(b)
+            end = int(seg_e[k])
+            while e < end and host[e] not in (32, 9, 13, 10):
+                e += 1
+            got = lib.gmr_bvh_parse_motion(vp(host.ctypes.data + int(b)), e - int(b), 1, out1.ctypes.data, 1, C.byref(nl), C.byref(nc))
+            if got != 1:
+                redo.add(int(k))
+                continue
+            idx.append(int(offs[k]) * ncol + int(t))
+            val.append(float(out1[0]))
+        if idx:
+            rows.view(-1)[torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(dev)] = torch.from_numpy(np.asarray(val, dtype=np.float64)).to(dev)
+    for k in sorted(redo):  # the host parser decides (and words the error for a malformed file)
+        a, n, moff = int(ft.starts[k]), int(ft.sizes[k]), int(heads[k][7])
+        data = _parse_motion(host[a + moff:a + n], int(lens[k]), 9 * len(a0.bones) + 3, files[k])
+        if data.shape[1] != ncol:
+            raise ValueError(f"{files[k]}: expected {ncol} columns, found {data.shape[1]}")
+        rows[int(offs[k]):int(offs[k + 1])] = torch.from_numpy(data).to(dev)
+    if stats is not None:
+        stats.update({"text_bytes": int(ft.sizes.sum()), "numbers": int(N * ncol), "slow_tokens": ns, "files_reparsed_on_host": len(redo)})
+    return a0, rows, offs
+
+
+def load_lafan1_files(bvh_files, device: int = 0, threads: int = 8, columns=None, parse: str = "device", stats: Optional[dict] = None,
+                      _slot: int = 0) -> BvhBatch:
+    """A folder's worth of BVH files -> one GPU batch (the file loop of scripts/bvh_to_robot_dataset.py:59-80, where every file
+    is parsed with regexes and turned into per-frame dicts one after the other).  All files must share one skeleton (names,
+    parents, offsets, Euler order, channel layout), as a dataset does; the height estimate of every clip (lafan1.py:45-69, from its
+    own last frame) comes back with the batch.
+
+    ``parse="device"`` (default): the files are read into page-locked memory and copied to the GPU as they are; the MOTION blocks are
+    parsed there (``gmr_bvh_parse_motion_device``: same numbers as the host parser, bit for bit; what is off its exact path is
+    decided by the host parser) and ONE ``gmr_bvh_fk_rows`` launch does row slicing, degrees -> radians, Euler -> quaternion, the
+    skeleton FK, Y-up -> Z-up, cm -> m and the FootMod synthesis for all clips -- the host only reads files and HIERARCHY sections.
+    ``parse="host"``: the MOTION blocks are parsed by ``gmr_bvh_parse_motion`` on ``threads`` host threads (round 2's path)."""
     files = [str(f) for f in bvh_files]
     if not files:
         raise ValueError("no files")
-    with ThreadPoolExecutor(max_workers=max(1, min(threads, len(files)))) as ex:
-        anims = list(ex.map(read_bvh, files))
-    a0 = anims[0]
-    _check_one_skeleton(files, anims)
     dev = torch.device("cuda", device)
-    lens = np.array([len(a) for a in anims], dtype=np.int64)
-    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-    N, ncol = int(offs[-1]), int(a0.rows.shape[1])
-    rows_h = torch.empty((N, ncol), dtype=torch.float64, pin_memory=True)
-    for a, o in zip(anims, offs[:-1]):
-        rows_h[o:o + len(a)] = torch.from_numpy(a.rows)
-    rows = rows_h.to(dev, non_blocking=True)
+    if parse == "device":
+        ft = _read_files(files, threads, _slot)
+        a0, rows, offs = _rows_on_device(ft, dev, stats)
+        frametimes = [h[6] for h in ft.heads]
+    elif parse == "host":
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=max(1, min(threads, len(files)))) as ex:
+            anims = list(ex.map(read_bvh, files))
+        a0 = anims[0]
+        _check_one_skeleton(files, anims)
+        lens = np.array([len(a) for a in anims], dtype=np.int64)
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        N, ncol = int(offs[-1]), int(a0.rows.shape[1])
+        rows_h = torch.empty((N, ncol), dtype=torch.float64, pin_memory=True)
+        for a, o in zip(anims, offs[:-1]):
+            rows_h[o:o + len(a)] = torch.from_numpy(a.rows)
+        rows = rows_h.to(dev, non_blocking=True)
+        frametimes = [a.frametime for a in anims]
+    else:
+        raise ValueError("parse must be 'device' or 'host'")
     pos, quat, names = _device_fk(a0, rows, dev, columns)
     heights = _clip_heights(a0, rows, offs, dev, full=(pos, names) if columns is None else None)
-    return BvhBatch(pos, quat, names, offs, heights, [a.frametime for a in anims], files)
+    return BvhBatch(pos, quat, names, offs, heights, frametimes, files)
+
+
+def iter_lafan1_batches(bvh_files, batch_files: int = 32, device: int = 0, threads: int = 8, columns=None):
+    """The folder in batches of ``batch_files`` files, read ahead: while the caller works on batch k (its ``retarget_batch`` call,
+    writing the results), a background thread reads batch k + 1's files and parses their headers into the other pinned buffer."""
+    from concurrent.futures import ThreadPoolExecutor
+    files = [str(f) for f in bvh_files]
+    groups = [files[i:i + batch_files] for i in range(0, len(files), max(1, batch_files))]
+    if not groups:
+        return
+    dev = torch.device("cuda", device)
+    with ThreadPoolExecutor(max_workers=1) as bg:
+        nxt = bg.submit(_read_files, groups[0], threads, 0)
+        for g in range(len(groups)):
+            ft = nxt.result()
+            if g + 1 < len(groups):
+                nxt = bg.submit(_read_files, groups[g + 1], threads, (g + 1) & 1)
+            a0, rows, offs = _rows_on_device(ft, dev)
+            pos, quat, names = _device_fk(a0, rows, dev, columns)
+            heights = _clip_heights(a0, rows, offs, dev, full=(pos, names) if columns is None else None)
+            yield BvhBatch(pos, quat, names, offs, heights, [h[6] for h in ft.heads], ft.files)

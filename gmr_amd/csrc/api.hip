@@ -21,6 +21,7 @@
 #include "ik_kernel.hip.h"
 #include "bvh_kernel.hip.h"
 #include "smplx_kernel.hip.h"
+#include "bvh_parse_kernel.hip.h"
 #include "bvh_text.h"
 
 using gmr::u64;
@@ -1596,6 +1597,64 @@ int64_t gmr_bvh_parse_motion(const char *text, size_t len, int64_t max_lines, do
   if (n_lines) *n_lines = lines;
   if (n_cols) *n_cols = cols0 < 0 ? 0 : cols0;
   return count;
+}
+
+int gmr_bvh_parse_motion_device(const char *text, int64_t text_bytes, int n_files, const int64_t *seg_begin, const int64_t *seg_end,
+                                const int64_t *n_lines, int64_t n_cols, const int64_t *row_begin, double *rows_out, int32_t *status_out,
+                                int64_t *n_tokens_out, int64_t *slow_out, int64_t max_slow, int64_t *n_slow, void *stream) {
+  if (!text || !seg_begin || !seg_end || !n_lines || !row_begin || !rows_out || !status_out || !n_slow || n_files < 0 || n_cols < 1 ||
+      max_slow < 0 || (max_slow > 0 && !slow_out))
+    return GMR_EINVAL;
+  *n_slow = 0;
+  if (n_files == 0) return GMR_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  std::vector<gmr::TxtFile> files((size_t)n_files);
+  int64_t nchunk = 0;
+  for (int f = 0; f < n_files; ++f) {
+    if (seg_begin[f] < 0 || seg_end[f] < seg_begin[f] || seg_end[f] > text_bytes || n_lines[f] < 0 || row_begin[f] < 0) return GMR_EINVAL;
+    gmr::TxtFile &t = files[(size_t)f];
+    t.seg_begin = seg_begin[f]; t.seg_end = seg_end[f]; t.chunk0 = nchunk;
+    t.tok_limit = n_lines[f] * n_cols; t.out_base = row_begin[f] * n_cols; t.n_tokens = 0; t.status = 0; t.pad = 0;
+    nchunk += std::max<int64_t>(1, (seg_end[f] - seg_begin[f] + gmr::kTxtChunk - 1) / gmr::kTxtChunk);  // (an empty block still owns a chunk: chunk -> file stays a search)
+  }
+  if (nchunk > 0x7fffffff) return GMR_EUNSUPPORTED;
+  // one stream-ordered scratch block: file table | per-chunk counts | per-chunk bases | slow list | slow counter
+  const size_t o_files = 0, o_counts = (sizeof(gmr::TxtFile) * (size_t)n_files + 15) & ~(size_t)15;
+  const size_t o_bases = (o_counts + sizeof(int) * (size_t)nchunk + 15) & ~(size_t)15;
+  const size_t o_slow = o_bases + sizeof(int64_t) * (size_t)nchunk;
+  const size_t o_cnt = o_slow + sizeof(int64_t) * 3 * (size_t)max_slow;
+  const size_t total = o_cnt + 16;
+  char *scr = nullptr;
+  if (hipMallocAsync((void **)&scr, total, st) != hipSuccess) return GMR_EDEVICE;
+  int rc = GMR_OK;
+  unsigned long long cnt = 0;
+  do {
+    if (hipMemcpyAsync(scr + o_files, files.data(), sizeof(gmr::TxtFile) * (size_t)n_files, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemsetAsync(scr + o_cnt, 0, 16, st) != hipSuccess) { rc = GMR_EDEVICE; break; }
+    gmr::TxtFile *dfiles = reinterpret_cast<gmr::TxtFile *>(scr + o_files);
+    int *counts = reinterpret_cast<int *>(scr + o_counts);
+    int64_t *bases = reinterpret_cast<int64_t *>(scr + o_bases);
+    const unsigned char *utext = reinterpret_cast<const unsigned char *>(text);
+    hipLaunchKernelGGL(gmr::bvh_txt_count_kernel, dim3((unsigned)nchunk), dim3(64), 0, st, utext, dfiles, n_files, counts);
+    hipLaunchKernelGGL(gmr::bvh_txt_scan_kernel, dim3((unsigned)n_files), dim3(64), 0, st, dfiles, counts, bases);
+    hipLaunchKernelGGL(gmr::bvh_txt_parse_kernel, dim3((unsigned)nchunk), dim3(64), 0, st, utext, dfiles, n_files, bases, n_cols, rows_out,
+                       reinterpret_cast<int64_t *>(scr + o_slow), max_slow, reinterpret_cast<unsigned long long *>(scr + o_cnt));
+    if (hipGetLastError() != hipSuccess) { rc = GMR_EDEVICE; break; }
+    if (hipMemcpyAsync(files.data(), dfiles, sizeof(gmr::TxtFile) * (size_t)n_files, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(&cnt, scr + o_cnt, sizeof(cnt), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) { rc = GMR_EDEVICE; break; }
+    const int64_t keep = std::min<int64_t>((int64_t)cnt, max_slow);
+    if (keep > 0 && (hipMemcpyAsync(slow_out, scr + o_slow, sizeof(int64_t) * 3 * (size_t)keep, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                     hipStreamSynchronize(st) != hipSuccess)) { rc = GMR_EDEVICE; break; }
+    *n_slow = (int64_t)cnt;
+    for (int f = 0; f < n_files; ++f) {
+      const gmr::TxtFile &t = files[(size_t)f];
+      status_out[f] = (t.status & 1) | (t.n_tokens < t.tok_limit ? 2 : 0);
+      if (n_tokens_out) n_tokens_out[f] = t.n_tokens;
+    }
+  } while (0);
+  (void)hipFreeAsync(scr, st);
+  return rc;
 }
 
 static int bvh_fk_launch(const int32_t *parents, int n_joints, const int32_t *euler_order, const int32_t *extra_pos_src,

@@ -1243,13 +1243,24 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
     }
     if (w.check_stride > 0 && left == 0) {
       double *B = ik_args(Lk)->qfinal + (size_t)(w.burn_row + kc) * nq;
+      // The floating base's quaternion and its negative are one rotation.  The sequential run carries its sign along from qpos0; a
+      // speculative chunk took the sign of the target it was started on (key-points from files come in either), so the states are
+      // compared up to that sign, and a chunk adopted with the other sign has its stored quaternions turned to the sequence's.
+      double dq = 0.0;
+      for (int i = lane; i < nq; i += 64) dq += (i >= 3 && i < 7) ? q[i] * B[i] : 0.0;
+      const double sgn = wave_sum(dq) < 0.0 ? -1.0 : 1.0;
       double d = 0.0;
-      for (int i = lane; i < nq; i += 64) d = fmax(d, fabs(q[i] - B[i]));
+      for (int i = lane; i < nq; i += 64) d = fmax(d, fabs(q[i] - ((i >= 3 && i < 7) ? sgn * B[i] : B[i])));
       const int len = min(w.check_stride, nfr - kf);
       if (wave_max(d) < ik_args(Lk)->prm.check_tol) {  // wave-uniform
         const double *Fk = ik_args(Lk)->qfinal + (size_t)(w.final_row + kc) * nq;
         __syncthreads();
-        for (int i = lane; i < nq; i += 64) q[i] = Fk[i];
+        for (int i = lane; i < nq; i += 64) q[i] = (i >= 3 && i < 7) ? sgn * Fk[i] : Fk[i];
+        if (sgn < 0.0) {  // (rare: wave-uniform)
+          double *qo = ik_args(Lk)->qout + (size_t)(w.frame_begin + kf) * nq;
+          for (int e = lane; e < 4 * len; e += 64) { double *p = qo + (size_t)(e >> 2) * nq + 3 + (e & 3); *p = -*p; }
+          if (lane >= 3 && lane < 7) B[lane] = -B[lane];  // the state this chunk's output starts from, in the sequence's sign (a changed B row = rows to re-send, distributed.py)
+        }
         __syncthreads();
         poses_valid = false;
         ++kc;

@@ -364,3 +364,100 @@ def smplx_arrays_torch(n_frames: int, device, n_joints: int = 55, joints_stride:
     joints = torch.randn((1, joints_stride, 3), generator=g, dtype=torch.float64, device=device) * 0.5 \
         + 0.3 * torch.sin(2 * np.pi * 0.2 * t + torch.rand((1, joints_stride, 3), generator=g, dtype=torch.float64, device=device) * 6.28)
     return global_orient, full_pose.contiguous(), joints.contiguous()
+
+
+def _bvh_header(names: List[str], parents, offsets, channels6: bool) -> str:
+    """HIERARCHY text of a skeleton: 3 rotation channels per joint (ZYX) + 3 root translation channels, or 6 channels everywhere."""
+    children = {i: [j for j, p in enumerate(parents) if p == i] for i in range(len(names))}
+    out = ["HIERARCHY"]
+
+    def emit(i, depth):
+        ind = "\t" * depth
+        out.append(f"{ind}{'ROOT' if parents[i] < 0 else 'JOINT'} {names[i]}")
+        out.append(ind + "{")
+        o = offsets[i]
+        out.append(f"{ind}\tOFFSET {o[0]:.6f} {o[1]:.6f} {o[2]:.6f}")
+        if channels6 or parents[i] < 0:
+            out.append(f"{ind}\tCHANNELS 6 Xposition Yposition Zposition Zrotation Yrotation Xrotation")
+        else:
+            out.append(f"{ind}\tCHANNELS 3 Zrotation Yrotation Xrotation")
+        if not children[i]:
+            out.extend([f"{ind}\tEnd Site", ind + "\t{", f"{ind}\t\tOFFSET 0.000000 5.000000 0.000000", ind + "\t}"])
+        for c in children[i]:
+            emit(c, depth + 1)
+        out.append(ind + "}")
+    emit(0, 0)
+    return "\n".join(out)
+
+
+def _write_rows(path: str, header: str, rows: np.ndarray, frame_time: float = 1.0 / 30.0) -> None:
+    body = "\n".join(" ".join(["%.6f"] * rows.shape[1]) % tuple(r) for r in rows)
+    with open(path, "w") as fh:
+        fh.write(f"{header}\nMOTION\nFrames: {rows.shape[0]}\nFrame Time: {frame_time:.6f}\n{body}\n")
+
+
+def write_lafan_shaped_files(folder: str, n_files: int, frames: int, seed: int = 0) -> List[str]:
+    """LAFAN1-shaped BVH files (22 bones, root translation + ZYX Euler angles, cm, Y-up) with band-limited random joint angles:
+    the shape of the text a LAFAN1 folder holds.  The motion is NOT something a robot can follow (bone frames are arbitrary), so
+    these files measure the loader, not the solver."""
+    import os
+    names = [n for n, _, _ in LAFAN1_BONES]
+    parents = [p for _, p, _ in LAFAN1_BONES]
+    offsets = [o for _, _, o in LAFAN1_BONES]
+    header = _bvh_header(names, parents, offsets, channels6=False)
+    rng = np.random.default_rng(seed)
+    J, files = len(names), []
+    t = np.arange(frames) / 30.0
+    for k in range(n_files):
+        a, f, ph = rng.uniform(2, 25, (1, 3 * J)), rng.uniform(0.1, 1.2, (1, 3 * J)), rng.uniform(0, 6.28, (1, 3 * J))
+        ang = a * np.sin(2 * np.pi * f * t[:, None] + ph)
+        ang[:, 1] += rng.uniform(-180, 180) + np.cumsum(rng.normal(0, 0.5, frames))  # heading (Y-up: yaw is the Y rotation)
+        root = np.stack([np.cumsum(rng.normal(0, 1.0, frames)), 92 + 2 * np.sin(t), np.cumsum(rng.normal(0, 1.0, frames))], -1)
+        p = os.path.join(folder, f"clip{k:03d}.bvh")
+        _write_rows(p, header, np.concatenate([root, ang], axis=1))
+        files.append(p)
+    return files
+
+
+def write_keypoint_files(folder: str, pos: np.ndarray, quat: np.ndarray, names: List[str], seq_offsets, prefix: str = "kp",
+                         head_height: Optional[float] = None) -> List[str]:
+    """Robot-consistent key-points (``synth_clips*`` output for a bvh_to_* config: metres, Z-up, wxyz) as BVH files the loader turns
+    back into the same key-points: a flat hierarchy -- every bone a child of a root at the origin, 6 channels each, so a bone's
+    channels are its global pose in the file's frame (cm, Y-up, ZYX Euler degrees) -- with ``<Side>FootMod`` stored the way LAFAN1
+    implies it (lafan1.py:36-39): ``<Side>Foot`` carries its position, ``<Side>Toe`` its orientation.  ``head_height`` adds a
+    ``Head`` bone that far above the lower foot, so that the loader's height estimate (lafan1.py:45-69) returns it."""
+    import os
+    from scipy.spatial.transform import Rotation as R
+    bones, src_p, src_q = ["Root"], [-1], [-1]
+    for i, n in enumerate(names):
+        if n.endswith("FootMod"):
+            side = n[: -len("FootMod")]
+            bones += [side + "Foot", side + "Toe"]; src_p += [i, i]; src_q += [i, i]
+        else:
+            bones.append(n); src_p.append(i); src_q.append(i)
+    feet = [i for i, n in enumerate(names) if n.endswith("FootMod")]
+    if head_height is not None and feet and "Head" not in bones:
+        bones.append("Head"); src_p.append(-2); src_q.append(0)
+    parents = [-1] + [0] * (len(bones) - 1)
+    header = _bvh_header(bones, parents, [(0.0, 0.0, 0.0)] * len(bones), channels6=True)
+    offs = np.asarray(seq_offsets, dtype=np.int64)
+    h = np.sqrt(0.5)
+    rq_inv = np.array([h, -h, 0.0, 0.0])   # the loader turns the file's frame by [h, h, 0, 0] (Y-up -> Z-up)
+    files = []
+    for s in range(len(offs) - 1):
+        a, b = int(offs[s]), int(offs[s + 1])
+        T = b - a
+        rows = np.zeros((T, len(bones), 6))
+        for j in range(1, len(bones)):
+            if src_p[j] == -2:   # the synthetic head: above the root, head_height over the lower foot
+                p = pos[a:b, 0].astype(np.float64).copy()
+                p[:, 2] = pos[a:b, feet, 2].astype(np.float64).min(axis=1) + head_height
+            else:
+                p = pos[a:b, src_p[j]].astype(np.float64)
+            rows[:, j, 0], rows[:, j, 1], rows[:, j, 2] = 100.0 * p[:, 0], 100.0 * p[:, 2], -100.0 * p[:, 1]   # inverse of (x, -z, y) / 100
+            q = qmul(np.broadcast_to(rq_inv, (T, 4)), quat[a:b, src_q[j]].astype(np.float64))
+            rows[:, j, 3:6] = R.from_quat(q[:, [1, 2, 3, 0]]).as_euler("ZYX", degrees=True)   # q = qz (x) qy (x) qx: the channel order
+        f = os.path.join(folder, f"{prefix}{s:03d}.bvh")
+        _write_rows(f, header, rows.reshape(T, -1))
+        files.append(f)
+    return files

@@ -34,7 +34,7 @@
  *   gmr_smplx_keypoints, gmr_smplx_keypoints_cols  the numeric part of get_smplx_data_offline_fast (general_motion_retargeting/utils/smpl.py:109-198)
  *                      after the SMPL-X body model: slerp/lerp to the target frame rate, orientation chaining
  *   gmr_bvh_parse_header the HIERARCHY section of read_bvh (general_motion_retargeting/utils/lafan_vendor/extract.py:60-139)
- *   gmr_bvh_parse_motion the MOTION block of read_bvh (general_motion_retargeting/utils/lafan_vendor/extract.py:140-166): the
+ *   gmr_bvh_parse_motion, gmr_bvh_parse_motion_device  the MOTION block of read_bvh (general_motion_retargeting/utils/lafan_vendor/extract.py:140-166): the
  *                      per-line regex + float() loop that dominates BVH loading in the reference
  *   gmr_bvh_fk, gmr_bvh_fk_rows  the numeric part of load_lafan1_file (general_motion_retargeting/utils/lafan1.py:8-40):
  *                      euler_to_quat + quat_fk (utils/lafan_vendor/utils.py:56-103), Y-up -> Z-up, cm -> m,
@@ -240,6 +240,24 @@ int gmr_bvh_parse_header(const char *text, size_t len, int max_joints, char *nam
  * written, or -1 on a malformed token, a line whose length differs from the first, or an overflow of max_out.            */
 int64_t gmr_bvh_parse_motion(const char *text, size_t len, int64_t max_lines, double *out, int64_t max_out, int64_t *n_lines,
                              int64_t *n_cols);
+
+/* The same parse on the device, for a batch of files whose text is already in device memory (one H2D copy of the files as they
+ * are): identical values, bit for bit, for every token on the exact fast path (at most 19 significant digits, mantissa < 2^53, power
+ * of ten within 10^+-22: one correctly rounded multiply / divide, what float() returns); every other token is REPORTED, not guessed:
+ * the caller parses those with strtod (gmr_bvh_parse_motion's slow path) and patches rows_out.  Replaces the same reference lines
+ * (general_motion_retargeting/utils/lafan_vendor/extract.py:140-156).
+ *   text        device [text_bytes]   the files' bytes; seg_begin/seg_end host [n_files]: each file's MOTION block in it
+ *   n_lines     host [n_files]  rows to read per file (the header's Frames:);  n_cols: numbers per row (one skeleton per batch)
+ *   row_begin   host [n_files]  first row of each file in rows_out;  rows_out device [sum(n_lines)][n_cols] float64
+ *   status_out  host [n_files]  0 = ok; bit 0: some row does not hold n_cols numbers, bit 1: fewer than n_lines rows -- parse that
+ *               file with gmr_bvh_parse_motion, which reports what is wrong with it
+ *   n_tokens_out host [n_files] or NULL: numbers found in the whole block
+ *   slow_out    host [max_slow][3]  (file, index of the number in its file, byte offset in text) of the tokens off the fast path;
+ *               *n_slow = how many there were (more than max_slow: treat the files as status != 0)
+ * Runs on `stream` and synchronises it before returning.                                                                   */
+int gmr_bvh_parse_motion_device(const char *text, int64_t text_bytes, int n_files, const int64_t *seg_begin, const int64_t *seg_end,
+                                const int64_t *n_lines, int64_t n_cols, const int64_t *row_begin, double *rows_out, int32_t *status_out,
+                                int64_t *n_tokens_out, int64_t *slow_out, int64_t max_slow, int64_t *n_slow, void *stream);
 
 /* BVH skeleton FK (stateless).  Joints in hierarchy order (parents[0] = -1, parents[j] < j), one Euler triple per joint.
  *   parents, euler_order[3] (0=x,1=y,2=z, the order the channels are listed), extra_*_src[n_extra]: host

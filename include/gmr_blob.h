@@ -79,7 +79,10 @@ typedef struct gmr_blob_header {
  * of check_stride frames were already solved speculatively (n_burn must be 0):
  * at the k-th chunk boundary (k = 0, 1, ...) the state is compared with
  * qpos_final[burn_row + k], the state that chunk started its own output from.
- * Equal to gmr_ik_params.check_tol: the chunk's stored frames stand, the walk adopts
+ * Equal to gmr_ik_params.check_tol (the floating base's quaternion up to its sign: q and
+ * -q are one rotation, and a chunk started on a target carries the target's sign): the
+ * chunk's stored frames stand -- their base quaternions, the B row and the adopted state are
+ * turned to the sequence's sign where it differs -- the walk adopts
  * qpos_final[final_row + k] (its stored final state) and skips it.  Different: the
  * chunk is solved here from the true state, qpos_final[burn_row + k] and
  * qpos_final[final_row + k] are rewritten.  frames_done[item] = frames solved.

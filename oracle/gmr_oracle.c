@@ -681,9 +681,17 @@ int oracle_ik_solve(const oracle_model *m, const gmr_ik_params *prm, const void 
       if (w->check_stride > 0 && left == 0) { /* verification walk (gmr_blob.h): adopt a consistent chunk, solve an inconsistent one */
         double *B = qpos_final + (size_t)(w->burn_row + kc) * nq, d = 0.0;
         int len = w->check_stride < nfr - k ? w->check_stride : nfr - k;
-        for (int i = 0; i < nq; i++) d = fmax(d, fabs(q[i] - B[i]));
+        /* the base quaternion is compared up to sign (q and -q are one rotation; a chunk started on a target carries the target's
+         * sign, the sequence its own): a chunk adopted with the other sign has its stored quaternions turned to the sequence's */
+        double sgn = (q[3] * B[3] + q[4] * B[4] + q[5] * B[5] + q[6] * B[6]) < 0.0 ? -1.0 : 1.0;
+        for (int i = 0; i < nq; i++) d = fmax(d, fabs(q[i] - ((i >= 3 && i < 7) ? sgn * B[i] : B[i])));
         if (d < prm->check_tol) {
           memcpy(q, qpos_final + (size_t)(w->final_row + kc) * nq, nq * sizeof(double));
+          if (sgn < 0.0) {
+            for (int i = 3; i < 7; i++) { q[i] = -q[i]; B[i] = -B[i]; }
+            for (int r = 0; r < len; r++)
+              for (int i = 3; i < 7; i++) qpos_out[(size_t)(w->frame_begin + k + r) * nq + i] = -qpos_out[(size_t)(w->frame_begin + k + r) * nq + i];
+          }
           kc++;
           k += len - 1;
           continue;

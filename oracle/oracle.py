@@ -175,11 +175,12 @@ class Oracle:
         return q, s, errs
 
     def ik_solve(self, pos, quat, slot_col, items, qpos_init=None, params=None, n_threads=1, want_final=False, qpos_final=None,
-                 want_done=False):
+                 want_done=False, out=None, iters=None):
         """Batch solve with the work-item semantics of ``gmr_ik_solve``.
 
         pos ``[N, n_cols, 3]``, quat ``[N, n_cols, 4]`` (float32 or float64, same dtype),
         items: structured array of ``WORK_ITEM_DTYPE``.  Returns (qpos_out [N,nq], iters [N], qpos_final or None).
+        ``out`` / ``iters``: caller-owned result arrays (a verification walk writes into the rows its chunks produced).
         """
         prm = params or IKParams()
         assert pos.dtype == quat.dtype and pos.dtype in (np.float32, np.float64)
@@ -188,8 +189,9 @@ class Oracle:
         N, n_cols = pos.shape[0], pos.shape[1]
         slot_col = np.ascontiguousarray(slot_col, dtype=np.int32)
         items = np.ascontiguousarray(items, dtype=WORK_ITEM_DTYPE)
-        qout = np.full((N, self.nq), np.nan)
-        iters = np.zeros(N, dtype=np.int32)
+        qout = np.full((N, self.nq), np.nan) if out is None else out
+        iters = np.zeros(N, dtype=np.int32) if iters is None else iters
+        assert qout.dtype == np.float64 and qout.flags.c_contiguous and qout.shape == (N, self.nq) and iters.dtype == np.int32 and iters.shape == (N,)
         qi = _c64(qpos_init) if qpos_init is not None else None
         nfin = int(max(items["final_row"].max(), items["burn_row"].max())) + 1 if len(items) else 0
         qf = np.zeros((max(nfin, 1), self.nq)) if want_final else None

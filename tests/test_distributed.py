@@ -88,11 +88,8 @@ def test_gather_plan_is_per_clip_and_fast():
 def _oracle_solver(orc, pos, quat, sc):
     """The ``solve`` callable of solve_chunked_sharded backed by the CPU oracle's work-item restatement."""
     def solve(items, qinit, qfinal, out, iters, done):
-        qo, it, _, dn = orc.ik_solve(pos, quat, sc, items, qpos_init=None if qinit is None else qinit.numpy().copy(),
-                                     qpos_final=qfinal.numpy(), want_done=True)
-        m = ~np.isnan(qo[:, 0])
-        out.numpy()[m] = qo[m]
-        iters.numpy()[m] = it[m]
+        _, _, _, dn = orc.ik_solve(pos, quat, sc, items, qpos_init=None if qinit is None else qinit.numpy().copy(),
+                                   qpos_final=qfinal.numpy(), want_done=True, out=out.numpy(), iters=iters.numpy())
         if done is not None:
             done.numpy()[:] = dn
     return solve

@@ -258,3 +258,126 @@ def test_adapter_columns_feed_the_ik_directly(golden_dir):
     ps, qs, ns, _ = get_smplx_data_offline_fast(fp[:, 0], fp.reshape(T, -1), jt, SMPLX_PARENTS, src_fps=120.0, columns=g2._cm.slot_names)
     assert ns == list(g2._cm.slot_names) and ps.shape == (T // 4, 14, 3)
     assert torch.equal(g2.retarget_batch(pf, qf, nf), g2.retarget_batch(ps, qs, ns))
+
+
+# ------------------------------------------------------------------ the MOTION block parsed on the device (gmr_bvh_parse_motion_device)
+def _device_parse(lib, dev, blob: bytes, segs, n_lines, n_cols, max_slow=4096):
+    nf = len(segs)
+    text = torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy()).to(dev)
+    sb = np.array([a for a, _ in segs], np.int64); se = np.array([b for _, b in segs], np.int64)
+    nl = np.asarray(n_lines, np.int64)
+    rb = np.concatenate([[0], np.cumsum(nl)])[:-1].astype(np.int64)
+    rows = torch.full((int(nl.sum()), n_cols), float("nan"), dtype=torch.float64, device=dev)
+    status = np.zeros(nf, np.int32); ntok = np.zeros(nf, np.int64)
+    slow = np.zeros((max(max_slow, 1), 3), np.int64); n_slow = C.c_int64(0)
+    rc = lib.gmr_bvh_parse_motion_device(vp(text.data_ptr()), len(blob), nf, sb.ctypes.data_as(vp), se.ctypes.data_as(vp), nl.ctypes.data_as(vp), n_cols, rb.ctypes.data_as(vp),
+                                         vp(rows.data_ptr()), status.ctypes.data_as(vp), ntok.ctypes.data_as(vp), slow.ctypes.data_as(vp), max_slow, C.byref(n_slow), None)
+    return rc, rows.cpu().numpy(), status, ntok, slow[: min(n_slow.value, max_slow)], n_slow.value
+
+
+def test_device_motion_parser_equals_python_float():
+    """Every number the device parser writes equals Python's float() of the same token, bit for bit; tokens it does not decide are
+    reported with their place; blank lines, tabs, CR LF, a missing final newline, tokens that straddle lane and chunk edges (rows
+    of every length around 64 and 4096 bytes), extra rows behind n_lines are as on the host."""
+    lib = _native.load()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    fmts = ["%.6f", "%.4f", "%d", "%.10f", "%.1f", "%.3e", "%.8E", "%+.5f", "%.15g", "%.17g"]
+    for case in range(12):
+        n_cols = int(rng.integers(1, 140))
+        n_lines = int(rng.integers(1, 400))
+        sep = [" ", "  ", "\t", " \t "][case % 4]
+        eol = ["\n", "\r\n", " \n"][case % 3]
+        vals = rng.normal(0, 1, (n_lines + 3, n_cols)) * 10.0 ** rng.integers(-8, 9, (n_lines + 3, n_cols))
+        vals[rng.random(vals.shape) < 0.1] = 0.0
+        lines = []
+        for r in range(n_lines + 3):
+            toks = [(fmts[int(rng.integers(len(fmts)))] % v) for v in vals[r]]
+            lines.append(("  " if r % 5 == 0 else "") + sep.join(toks))
+            if r % 7 == 3:
+                lines.append("   ")  # a blank line
+        text = (eol.join(lines) + (eol if case % 2 else "")).encode()
+        junk = b"x" * int(rng.integers(0, 40))  # the segment does not start at offset 0
+        blob = junk + text + b"   trailing bytes of the next file"
+        rc, rows, status, ntok, slow, ns = _device_parse(lib, dev, blob, [(len(junk), len(junk) + len(text))], [n_lines], n_cols)
+        assert rc == 0 and status[0] == 0 and ns == len(slow), (case, status, ns)
+        exp = np.array([[float(t) for t in ln.split()] for ln in lines if ln.strip()][:n_lines])
+        got = rows.copy()
+        for k, t, b in slow:   # what the device left to the host: long mantissas (%.17g and friends)
+            tok = blob[int(b):].split()[0]
+            assert float(tok) == exp.reshape(-1)[int(t)]
+            got.reshape(-1)[int(t)] = float(tok)
+        assert got.tobytes() == exp.tobytes(), case
+        assert ntok[0] == sum(len(ln.split()) for ln in lines)
+
+
+def test_device_motion_parser_structure_and_slow_path():
+    lib = _native.load()
+    dev = torch.device("cuda", 0)
+    good = b"1 2 3\n4 5 6\n7 8 9\n"
+    # several files in one call, each with its own segment; an empty file; a file with fewer rows than asked
+    blob = good + b"#" * 5 + b"10 11 12\n" + b"13 14 15"
+    segs = [(0, len(good)), (len(good) + 5, len(blob)), (3, 3)]
+    rc, rows, status, ntok, slow, ns = _device_parse(lib, dev, blob, segs, [3, 2, 0], 3)
+    assert rc == 0 and list(status) == [0, 0, 0] and ns == 0 and np.array_equal(rows, np.arange(1, 16, dtype=np.float64).reshape(5, 3))
+    rc, rows, status, *_ = _device_parse(lib, dev, good, [(0, len(good))], [4], 3)
+    assert rc == 0 and status[0] == 2                      # fewer rows than the header says
+    for bad in (b"1 2 3\n4 5\n6 7 8 9\n", b"1 2\n3 4 5 6\n7 8 9\n", b"1 2 3 4 5 6\n7 8 9\n"):
+        rc, rows, status, *_ = _device_parse(lib, dev, bad, [(0, len(bad))], [3 if bad.count(b"\n") == 3 else 2], 3)
+        assert rc == 0 and status[0] & 1, bad              # ragged rows: the host parser is asked
+    # tokens the device must not decide: reported, in order of their place
+    odd = b"1e400 nan 0.1234567890123456789012 12345678901234567890 -inf 1_0 abc 1e 0x10 +.5 5. .e1 1.5e+3 -0 1e-30 9007199254740993\n"
+    toks = odd.split()
+    rc, rows, status, ntok, slow, ns = _device_parse(lib, dev, odd, [(0, len(odd))], [1], len(toks))
+    assert rc == 0 and status[0] == 0
+    decided = {int(t) for _, t, _ in slow}
+    for i, tk in enumerate(toks):
+        if i in decided:
+            assert odd[int(slow[[int(t) for _, t, _ in slow].index(i)][2]):].split()[0] == tk   # the byte offset names the token
+        else:
+            assert rows[0, i] == float(tk) and np.signbit(rows[0, i]) == np.signbit(float(tk)), tk
+    assert {toks.index(t) for t in (b"1e400", b"nan", b"-inf", b"1_0", b"abc", b"1e", b"0x10", b".e1", b"0.1234567890123456789012", b"12345678901234567890", b"1e-30", b"9007199254740993")} <= decided
+    assert not ({toks.index(t) for t in (b"+.5", b"5.", b"1.5e+3", b"-0")} & decided)
+    # a token longer than a lane can follow (past its 32-byte halo) is left to the host too
+    long_tok = b"0." + b"0" * 120 + b"1 2\n"
+    rc, rows, status, ntok, slow, ns = _device_parse(lib, dev, long_tok, [(0, len(long_tok))], [1], 2)
+    assert rc == 0 and ns == 1 and int(slow[0][1]) == 0 and rows[0, 1] == 2.0
+
+
+def test_bvh_folder_device_parse_equals_host_parse(golden_dir, tmp_path):
+    """load_lafan1_files(parse="device") == parse="host" bit for bit on the golden files and on a synthetic folder (several files,
+    unequal lengths, a CR LF file, one number written with 25 digits); a ragged file raises the host parser's error; batches read
+    ahead (iter_lafan1_batches) give the same clips."""
+    import os
+    import shutil
+    from gmr_amd.bvh import iter_lafan1_batches, load_lafan1_files
+    sys_tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    import sys
+    sys.path.insert(0, sys_tools)
+    from config3_files_bench import write_files
+    for name in ("bvh_canonical_40f", "bvh_lafan_like", "bvh_pruned_mid_24f", "bvh_nine_channel"):
+        p = os.path.join(golden_dir, name + ".bvh")
+        st = {}
+        d, h = load_lafan1_files([p, p], parse="device", stats=st), load_lafan1_files([p, p], parse="host")
+        assert torch.equal(d.pos, h.pos) and torch.equal(d.quat, h.quat) and d.human_heights == h.human_heights and d.body_names == h.body_names
+        assert np.array_equal(d.seq_offsets, h.seq_offsets) and st["files_reparsed_on_host"] == 0
+    files = write_files(str(tmp_path), 5, 300)
+    raw = open(files[1], "rb").read()
+    open(files[1], "wb").write(raw.replace(b"\n", b"\r\n"))
+    txt = open(files[2], "rb").read().split(b"\n")
+    row = txt[-2].split()
+    row[7] = b"12.3456789012345678901234"
+    txt[-2] = b" ".join(row)
+    open(files[2], "wb").write(b"\n".join(txt[:-2]) + b"\n" + txt[-2] + b"\n")
+    st = {}
+    d, h = load_lafan1_files(files, parse="device", stats=st), load_lafan1_files(files, parse="host")
+    assert torch.equal(d.pos, h.pos) and torch.equal(d.quat, h.quat) and d.human_heights == h.human_heights and st["slow_tokens"] == 1
+    got = list(iter_lafan1_batches(files, batch_files=2))
+    assert [len(b) for b in got] == [2, 2, 1] and torch.equal(torch.cat([b.pos for b in got]), h.pos)
+    bad = str(tmp_path / "ragged.bvh")
+    shutil.copy(files[0], bad)
+    t = open(bad, "rb").read().split(b"\n")
+    t[-5] = b" ".join(t[-5].split()[:-1])
+    open(bad, "wb").write(b"\n".join(t))
+    with pytest.raises(ValueError, match="malformed motion block"):
+        load_lafan1_files([files[0], bad], parse="device")

@@ -219,3 +219,27 @@ def test_clip_start_on_root_target_is_opt_in():
     assert float((q_c - q_rt).abs().max().item()) < 1e-6 and g.last_chunk_info["resolved_frames"] <= 64
     with pytest.raises(ValueError):
         g.retarget_batch(pos, quat, names, clip_start="nowhere")
+
+
+def test_chunked_solve_is_blind_to_target_quaternion_signs():
+    """Key-points from files carry quaternions of either sign: the verified-chunked solve must neither re-solve the chunks whose
+    start took the other sign (the wall it hit in round 3: half of a BVH folder re-solved) nor hand back base quaternions of the
+    chunk's sign -- the result is the sequential run, bit for bit where chunks were adopted with the same sign, negated rows turned."""
+    cm = compiled("bvh", "unitree_g1")
+    eng = _engine(cm)
+    lengths = np.array([900, 1500, 700])
+    pos, quat, names, offs = synth.synth_clips_torch(cm, lengths, seed=9, device=eng.device, hard=np.array([False, True, False]), yaw0=1.0, dtype=torch.float64)
+    sc = cm.slot_columns(names)
+    flip = torch.from_numpy(np.random.default_rng(1).choice([-1.0, 1.0], size=tuple(quat.shape[:2]))).to(eng.device)
+    quat_s = quat * flip[..., None]
+    q_seq, it_seq, _ = eng.ik_solve(pos, quat_s, sc, make_items(offs))
+    q_ref, _, _ = eng.ik_solve(pos, quat, sc, make_items(offs))
+    assert torch.equal(q_seq, q_ref)                                       # the sequential solve does not see the signs
+    q_c, it_c, info_c = eng.ik_solve_chunked(pos, quat, sc, offs, chunk=64, burn_in=32)
+    q_s, it_s, info_s = eng.ik_solve_chunked(pos, quat_s, sc, offs, chunk=64, burn_in=32)
+    assert info_s["resolved_frames"] <= info_c["resolved_frames"] + 64 and info_s["resolved_frames"] < 0.1 * int(offs[-1])
+    assert float((q_s - q_seq).abs().max().item()) < 1e-6 and torch.equal(it_s & 0x3FFFFFFF, it_seq & 0x3FFFFFFF)   # signs of qpos[3:7] included
+    # a bounded oracle sample of the scrambled set
+    e = int(offs[1])
+    q_o, it_o, _ = Oracle(cm.blob).ik_solve(pos[:e].cpu().numpy(), quat_s[:e].cpu().numpy(), sc, make_items(offs[:2]))
+    assert np.abs(q_s[:e].cpu().numpy() - q_o).max() < 1e-6

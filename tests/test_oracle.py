@@ -260,6 +260,36 @@ def test_verification_walk_equals_sequential():
     assert resolved[INIT_QPOS0] > 0 and resolved[INIT_ROOT_TARGET] <= resolved[INIT_QPOS0]
 
 
+def test_verification_walk_is_blind_to_the_sign_of_target_quaternions():
+    """Key-points that come from files carry quaternions of either sign (q and -q are one rotation).  A chunk started on its root
+    target takes that sign, the sequential run keeps its own: the walk compares up to the sign and turns what it adopts, so the
+    result is still the sequential run -- values, the base quaternion's sign included -- and no more is re-solved than with
+    consistently signed inputs (gmr_blob.h)."""
+    from gmr_amd.schedule import make_items as sched_items, plan_walks
+    cm = compiled("bvh", "unitree_g1")
+    orc = Oracle(cm.blob)
+    pos, quat, names, offs, _ = synth.synth_clips(cm, 2, 120, seed=21, hard=False, dtype=np.float64)
+    sc = cm.slot_columns(names)
+    chunk, burn = 8, 12
+    done_by = {}
+    for label in ("consistent", "scrambled"):
+        qq = quat.copy()
+        if label == "scrambled":
+            qq *= np.random.default_rng(0).choice([-1.0, 1.0], size=quat.shape[:2])[..., None]
+        q_seq, it_seq, _ = orc.ik_solve(pos, qq, sc, make_items(offs, WORK_ITEM_DTYPE))
+        items = np.ascontiguousarray(sched_items(offs, chunk=chunk, burn_in=burn, track=True), dtype=WORK_ITEM_DTYPE)
+        n = len(items)
+        qf = np.zeros((2 * n, orc.nq))
+        q0, it0, _ = orc.ik_solve(pos, qq, sc, items, qpos_final=qf)
+        walks = np.ascontiguousarray(plan_walks(items, offs, chunk), dtype=WORK_ITEM_DTYPE)
+        _, _, _, done = orc.ik_solve(pos, qq, sc, walks, qpos_init=qf.copy(), qpos_final=qf, want_done=True, out=q0, iters=it0)
+        assert np.abs(q0 - q_seq).max() < 1e-6 and np.array_equal(it0, it_seq), label   # (the sign of qpos[3:7] too)
+        done_by[label] = int(done.sum())
+    q_a, _, _ = orc.ik_solve(pos, quat, sc, make_items(offs, WORK_ITEM_DTYPE))
+    assert np.abs(q_a - q_seq).max() < 1e-9   # the sequential run itself does not see the signs
+    assert done_by["scrambled"] <= done_by["consistent"] + 2 * chunk
+
+
 def test_root_target_init_and_height_scale_items():
     """The two per-item knobs of gmr_work_item (gmr_blob.h).  INIT_ROOT_TARGET: the first frame starts from qpos0 with the base on
     the prepared root-task target.  height_scale: the item is solved with the scale table of a model compiled for that height."""
