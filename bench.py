@@ -507,6 +507,33 @@ def main():
             "with_rotations": {"frames": nf // 2, "kernel_ms": fk_ms2, "bytes_per_frame": fk_bytes2,
                                "frac": fk_bytes2 * (nf // 2) / (fk_ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
+        if not args.no_cpu and not args.hot_only:
+            # the CPU path beside it: the oracle's float32 restatement of KinematicsModel.forward_kinematics (positions only) on this
+            # host's cores, frames split over threads (the ctypes call releases the GIL); a bounded sample of the same frames
+            try:
+                from concurrent.futures import ThreadPoolExecutor
+                from oracle.oracle import Oracle  # checker / comparator only
+                orc_fk = Oracle(cm.blob)
+                cores = host_cores()
+                n_cpu = min(nf, 400_000 * cores)
+                h_rp, h_rr, h_d = root_pos32[:n_cpu].cpu().numpy(), root_rot32[:n_cpu].cpu().numpy(), dof32[:n_cpu].cpu().numpy()
+                n1 = min(n_cpu, 200_000)
+                t1 = time.perf_counter()
+                orc_fk.fk_kin(h_rp[:n1], h_rr[:n1], h_d[:n1], want_rot=False)
+                t_one = time.perf_counter() - t1
+                cuts = np.linspace(0, n_cpu, cores + 1).astype(np.int64)
+                t1 = time.perf_counter()
+                with ThreadPoolExecutor(max_workers=cores) as ex:
+                    parts = list(ex.map(lambda k: orc_fk.fk_kin(h_rp[cuts[k]:cuts[k + 1]], h_rr[cuts[k]:cuts[k + 1]], h_d[cuts[k]:cuts[k + 1]], want_rot=False)[0], range(cores)))
+                t_all = time.perf_counter() - t1
+                chk = float(np.abs(parts[0][:4096] - bp_out[:4096].cpu().numpy()).max())
+                result["fk"]["cpu_baseline"] = {"value": n_cpu / t_all, "unit": "frames/s", "cores": cores, "kind": "port",
+                                                "sample": f"{n_cpu} of the same frames, positions only, float32 C oracle, {cores} threads", "single_core_value": n1 / t_one,
+                                                "max_abs_diff_gpu_vs_cpu_m": chk,
+                                                "reference_measured": "reference torch FK (kinematics_model.py:213-246), G1 38 bodies, 8 CPU threads: 2.1e5 frames/s (SURVEY 6, measured in the build container)"}
+                del parts, h_rp, h_rr, h_d
+            except Exception as ex:
+                result["fk"]["cpu_baseline"] = {"error": repr(ex)}
         del root_pos32, root_rot32, dof32, bp_out, br_out
     if rank == 0 and world == 1 and (not args.hot_only or args.hot_adapters):
         # the two input-adapter kernels (rows f-1, f-2): HBM-bound by construction (1.9 - 8.4 KB per frame)

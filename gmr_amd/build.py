@@ -18,7 +18,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libgmr_amd.so")
 SOURCES = ["api.hip"]
-DEPS = ["api.hip", "ik_kernel.hip.h", "fk_kernel.hip.h", "bvh_kernel.hip.h", "smplx_kernel.hip.h", "tree_chain.hip.h", "bvh_parse_kernel.hip.h", "bvh_text.h"]
+DEPS = ["api.hip", "ik_kernel.hip.h", "fk_kernel.hip.h", "bvh_kernel.hip.h", "smplx_kernel.hip.h", "tree_chain.hip.h", "bvh_parse_kernel.hip.h", "bvh_text.h", "ik_variants.hip.h"]
 HEADERS = ["gmr_amd.h", "gmr_blob.h"]
 ARCH = "gfx950"
 

@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -45,6 +46,7 @@ struct gmr_model {
   int nvp = 0, n_act = 0, lds_bytes = 0, fk_lds_bytes = 0, fk_lds_bytes_min = 0;  // _min: the min-height mode has no output stage
   unsigned long long *dbg = nullptr;  // diagnostic builds (GMR_IK_STAMPS) only
   int min_nvp = 0;                    // group members are built for a common kernel variant (gmr_group_create)
+  hipMemPool_t pool = nullptr;        // the library's scratch pool of this device (scratch_pool)
   int fk_pos_parts = 1;               // gmr_fk without rotations: fk_pos_kernel<parts> (GMR_AMD_FK_PARTS=0 falls back to fk_kernel<0>)
   bool force_generic = false;         // GMR_AMD_GENERIC_QP=1: use the dense generic QP even where the structured one applies
 };
@@ -124,9 +126,33 @@ struct CallScratch {
   hipStream_t st = nullptr;
   ~CallScratch() { if (p) (void)hipFreeAsync(p, st); }
 };
+// The library's own pool, one per device, created on first use and kept for the life of the process: the few KB of per-call
+// scheduling data never touch the device's default pool, whose settings belong to the host application.  Released
+// blocks stay cached up to 64 MiB, so a call costs no device synchronisation.
+hipMemPool_t scratch_pool(int device) {
+  static std::mutex mu;
+  static std::map<int, hipMemPool_t> pools;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = pools.find(device);
+  if (it != pools.end()) return it->second;
+  hipMemPoolProps props{};
+  props.allocType = hipMemAllocationTypePinned;
+  props.handleTypes = hipMemHandleTypeNone;
+  props.location.type = hipMemLocationTypeDevice;
+  props.location.id = device;
+  hipMemPool_t pool = nullptr;
+  if (hipMemPoolCreate(&pool, &props) != hipSuccess) { (void)hipGetLastError(); pool = nullptr; }
+  if (pool) {
+    uint64_t keep = 64ull << 20;
+    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+  }
+  pools[device] = pool;
+  return pool;
+}
 int scratch_alloc(gmr_model *m, CallScratch &sc, size_t bytes, hipStream_t st) {
   sc.st = st;
-  HIP_TRY(m, hipMallocAsync(&sc.p, std::max<size_t>(bytes, 256), st));
+  if (m->pool) HIP_TRY(m, hipMallocFromPoolAsync(&sc.p, std::max<size_t>(bytes, 256), m->pool, st));
+  else HIP_TRY(m, hipMallocAsync(&sc.p, std::max<size_t>(bytes, 256), st));
   return GMR_OK;
 }
 
@@ -825,16 +851,21 @@ int build_device_model(gmr_model *m) {
 
   if (m->lds_bytes > 160 * 1024) { set_err(m, "model needs %d bytes of LDS per wavefront", m->lds_bytes); return GMR_EUNSUPPORTED; }
   // opt in to > 64 KiB of dynamic LDS where a variant needs it
+#define GMR_LDS_OPT_IN(k) hipFuncSetAttribute(reinterpret_cast<const void *>(&k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #ifdef GMR_IK_DEV_ONLY36
-#define GMR_X(v) hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<v, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define GMR_X(v) GMR_LDS_OPT_IN((gmr::ik_kernel<v, true>)) GMR_LDS_OPT_IN((gmr::ik_probe_kernel<v, true>)) GMR_LDS_OPT_IN((gmr::ik_group_kernel<v, true>)) GMR_LDS_OPT_IN((gmr::ik_session_kernel<v, true>))
 #else
-#define GMR_X(v)                                                                                                                        \
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<v, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::ik_kernel<v, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define GMR_X(v)                                                                                                                         \
+  GMR_LDS_OPT_IN((gmr::ik_kernel<v, false>)) GMR_LDS_OPT_IN((gmr::ik_kernel<v, true>)) GMR_LDS_OPT_IN((gmr::ik_probe_kernel<v, false>))       \
+  GMR_LDS_OPT_IN((gmr::ik_probe_kernel<v, true>)) GMR_LDS_OPT_IN((gmr::ik_group_kernel<v, false>)) GMR_LDS_OPT_IN((gmr::ik_group_kernel<v, true>)) \
+  GMR_LDS_OPT_IN((gmr::ik_session_kernel<v, false>)) GMR_LDS_OPT_IN((gmr::ik_session_kernel<v, true>))
 #endif
   GMR_FOR_EACH_NVP(GMR_X)
 #undef GMR_X
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&gmr::eval_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  GMR_LDS_OPT_IN(gmr::eval_kernel)
+  GMR_LDS_OPT_IN(gmr::fk_pos_kernel<1>) GMR_LDS_OPT_IN(gmr::fk_pos_kernel<2>)
+  GMR_LDS_OPT_IN(gmr::fk_kernel<0>) GMR_LDS_OPT_IN(gmr::fk_kernel<1>)
+#undef GMR_LDS_OPT_IN
   (void)hipGetLastError();
   return GMR_OK;
 }
@@ -880,12 +911,7 @@ static gmr_model *model_create_impl(const void *blob, size_t blob_bytes, int dev
   m->h = h;
   m->blob.assign(static_cast<const uint8_t *>(blob), static_cast<const uint8_t *>(blob) + blob_bytes);
   if (hipSetDevice(device) != hipSuccess) return fail(m, "hipSetDevice failed");
-  {  // per-call scratch comes from the device's stream-ordered pool (CallScratch): keep released blocks cached
-    hipMemPool_t pool = nullptr;
-    uint64_t keep = ~0ull;
-    if (hipDeviceGetDefaultMemPool(&pool, device) != hipSuccess || hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) != hipSuccess)
-      return fail(m, "stream-ordered memory pool unavailable on this device");
-  }
+  m->pool = scratch_pool(device);  // (nullptr: no pool support on this runtime -- per-call scratch then comes from the device's default pool as it is)
   if (const char *e = getenv("GMR_AMD_GENERIC_QP")) m->force_generic = e[0] == '1';
   if (force_generic) m->force_generic = true;
   m->min_nvp = min_nvp;
@@ -1397,8 +1423,13 @@ int gmr_fk(gmr_model *m, const float *root_pos, const float *root_rot_xyzw, cons
   if (!body_rot_out && m->fk_pos_parts > 0) {  // positions only: one wavefront per tile, the whole tile image in LDS (fk_pos_kernel)
     const int64_t nw = (n_frames + gmr::kFkWave - 1) / gmr::kFkWave;
     if (nw > 0x7fffffff) { set_err(m, "too many frames for one launch"); return GMR_EINVAL; }
-    const int nb = m->fk.nbody, parts = m->fk_pos_parts, prow = parts == 1 ? 3 * nb : 3 * ((nb + parts - 1) / parts);
-    const int lds = (std::max(1, m->fk.nslots) * 7 + prow) * gmr::kFkWave * (int)sizeof(float);
+    const int nb = m->fk.nbody;
+    auto image = [&](int parts) { return (std::max(1, m->fk.nslots) * 7 + (parts == 1 ? 3 * nb : 3 * ((nb + parts - 1) / parts))) * gmr::kFkWave * (int)sizeof(float); };
+    int parts = m->fk_pos_parts;
+    if (parts == 1 && image(1) > 160 * 1024) parts = 2;  // a tile image beyond the CU's LDS: two half images, else the grouped flush below
+    const int lds = image(parts);
+    if (lds > 160 * 1024) parts = 0;
+    if (parts == 0) goto grouped;
     if (parts == 1)
       hipLaunchKernelGGL((gmr::fk_pos_kernel<1>), dim3((unsigned)nw), dim3(gmr::kFkWave), lds, static_cast<hipStream_t>(stream), m->fk, root_pos,
                          root_rot_xyzw, dof, n_frames, body_pos_out);
@@ -1408,11 +1439,13 @@ int gmr_fk(gmr_model *m, const float *root_pos, const float *root_rot_xyzw, cons
     HIP_TRY(m, hipGetLastError());
     return GMR_OK;
   }
+grouped : {
   const int fk_lds = body_rot_out ? m->fk_lds_bytes : m->fk_lds_bytes - gmr::kFkRotStride * gmr::kFkThreads * (int)sizeof(float);
   hipLaunchKernelGGL((gmr::fk_kernel<0>), dim3((unsigned)nblk), dim3(gmr::kFkThreads), fk_lds, static_cast<hipStream_t>(stream), m->fk,
                      root_pos, root_rot_xyzw, dof, n_frames, body_pos_out, body_rot_out, (const int64_t *)nullptr, 0, (int *)nullptr);
   HIP_TRY(m, hipGetLastError());
   return GMR_OK;
+}
 }
 
 int gmr_fk_min_height(gmr_model *m, const float *root_pos, const float *root_rot_xyzw, const float *dof, const int64_t *seq_offsets,

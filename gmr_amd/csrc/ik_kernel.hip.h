@@ -42,23 +42,18 @@ namespace gmr {
 
 typedef unsigned long long u64;
 
-#ifdef GMR_IK_STAMPS  // diagnostic build only: per-phase cycle shares (tools/ik_stamps.py); never in the shipped library
-#define GMR_STAMP(i) do { const u64 t_ = __builtin_readcyclecounter(); stamp_acc[i] += t_ - stamp_last; stamp_last = t_; } while (0)
-#elif defined(GMR_IK_MARKS)  // diagnostic: phase boundaries as comments in the ISA (tools/isa_regions.py --marks)
-#define GMR_STAMP(i) asm volatile("; gmr-mark " #i)
+// Measurement instruments (per-phase cycle stamps, ISA phase marks, the phase-duplication builds of tools/build_variant.sh) live in
+// ik_variants.hip.h and exist in variant builds only (-DGMR_IK_VARIANTS); the shipped kernel sees empty macros.
+#ifdef GMR_IK_VARIANTS
+#include "ik_variants.hip.h"
 #else
 #define GMR_STAMP(i) do { } while (0)
-#endif
-
-// Throughput attribution (experiments only): -DGMR_DUP_PHASE=p runs phase p of every solve twice (all phases are idempotent),
-// so the launch-time difference to the normal build is what that phase costs at full occupancy (tools/gpu_dup.sh).
-#ifdef GMR_DUP_PHASE
-#define GMR_DUP(p) for (int rep_ = 0, nrep_ = launder(GMR_DUP_PHASE == (p) ? 2 : 1); rep_ < nrep_; ++rep_)
-#else
+#define GMR_STAMP_DECL() do { } while (0)
+#define GMR_STAMP_QP() do { } while (0)
+#define GMR_STAMP_FLUSH() do { } while (0)
 #define GMR_DUP(p)
-#endif
-#ifndef GMR_QP_LDS_BCAST
-#define GMR_QP_LDS_BCAST 1
+#define GMR_DUP_QP_TWICE()
+#define GMR_DUP_FK_TWICE()
 #endif
 #ifndef GMR_QP_GROUP
 #define GMR_QP_GROUP 6
@@ -74,20 +69,9 @@ typedef unsigned long long u64;
 // stride is 30 = 15 sixteen-byte slots, odd, so that the blocks of different composites start on different LDS slots: the F
 // phase (every dof lane reads element c of ITS composite) then has no bank conflicts (stride 28 = 14 slots: 91 extra LDS
 // cycles per solve on G1).  Stored "by column": element 3k + s, s = 0..2,
-// GMR_IK_MIXED (variant builds only, tools/build_variant.sh mixed -DGMR_IK_MIXED=1): the assembly of H and c -- task blocks,
-// composites, screws as stored, F = B S, the H pair dot products -- in float32 (blocks / S / F keep their LDS slots and strides,
-// so every host-made plan stays valid; they just fill the first half of each slot), everything that decides the trajectory
-// (FK, residuals and their norm, LM damping, the QP with its pivots, integration, the termination test) in float64.  The
-// oracle's emulation of the same split (tools/experiments/mixed_precision_emulation.py): max |dq| 3.4e-6 rad, no frame with a
-// different solve count in 96 000.
-#ifndef GMR_IK_MIXED
-#define GMR_IK_MIXED 0
-#endif
-#if GMR_IK_MIXED
-typedef float blk_t;
-#else
+// (Round 2's mixed-precision variant -- this assembly in float32: -0.5 % time, 5.4e-5 rad -- lives in the history up to commit d74eaa7,
+// DESIGN 10 item 7.)
 typedef double blk_t;
-#endif
 constexpr int kBT = 30, kBTLanes = 14;
 // k: 0 LL(s,s)  1 LL(s,s+1)  2..4 LA(s,s), LA(s,s+1), LA(s,s+2)  5 AA(s,s)  6 AA(s,s+1)  7 gl_s  8 ga_s   (indices mod 3)
 // -- the order in which three lanes per task (one per column s) produce it in task_block_quad
@@ -673,7 +657,7 @@ __device__ __forceinline__ void cross_t(const T a[3], const T b[3], T o[3]) {
   o[1] = a[2] * b[0] - a[0] * b[2];
   o[2] = a[0] * b[1] - a[1] * b[0];
 }
-// T = double: the block in float64 (shipped).  T = float (GMR_IK_MIXED): the same arithmetic in float32 from rounded inputs.
+// T = double: the block in float64 (T = float was round 2's mixed-precision experiment).
 template <class T>
 __device__ __forceinline__ void task_block_quad(int s, const double e64[6], double kap64, double bet64, const double rs64[3],
                                                 const double xb64[3], double wp64, double wr64, T *out) {
@@ -779,7 +763,6 @@ __device__ __forceinline__ int box_qp(int lane, int n_act, const double *Hm, dou
       }
     }
     double myinv = 1.0;
-#if GMR_QP_LDS_BCAST
     // Right-looking Cholesky kept symmetric.  Column k of L and y_k = (L^-1 b)_k reach every lane through two
     // 64-entry LDS rows (one unconditional ds_write_b64 each per lane, then wave-uniform ds_read_b128 pairs), so the
     // VALU only issues the FMAs.  The forward solve rides along as an extra column (b_i -= l_i y_k).  Lane k uses
@@ -806,26 +789,6 @@ __device__ __forceinline__ int box_qp(int lane, int n_act, const double *Hm, dou
       b = lane == k ? yk : b - l * yk;
       R[k] = lane > k ? lk : R[k];
     }
-#else
-#pragma unroll
-    for (int k = 0; k < NVP; k++) {
-      const double dkk = rdlane(R[k], k);
-      const double inv = fast_rsqrt(dkk);
-      const double lk = R[k] * inv;
-      const double l = lane == k ? dkk * inv - 1.0 : (lane < k ? 0.0 : lk);
-      myinv = lane == k ? inv : myinv;
-#pragma unroll
-      for (int j = k + 1; j < NVP; j++) R[j] -= l * rdlane(l, j);
-      R[k] = lane > k ? lk : R[k];
-    }
-    // forward L y = b (rows below k use L[i][k] = R_i[k])
-#pragma unroll
-    for (int k = 0; k < NVP; k++) {
-      const double yk = rdlane(b * myinv, k);
-      const double coef = lane > k ? R[k] : 0.0;
-      b = lane == k ? yk : b - coef * yk;
-    }
-#endif
     // backward L' z = y (rows above k use L[k][i] = R_i[k])
 #pragma unroll
     for (int k = NVP - 1; k >= 0; k--) {
@@ -1184,10 +1147,7 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
       fkj.act[r] = __ballot(a != 0xff);
     }
   }
-#ifdef GMR_IK_STAMPS
-  u64 stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  u64 stamp_last = __builtin_readcyclecounter();
-#endif
+  GMR_STAMP_DECL();
   const int nq = m.nq, n_act = m.n_act, nslot = m.nslot, root_slot = m.root_slot, npairp = m.npairp, nbody = m.nbody, fkrounds = m.fkrounds;
   // active-dof constants of this lane (row of the QP); the rest is re-read where it is used
   const bool real_row = lane < n_act;
@@ -1419,11 +1379,7 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
         GMR_DUP(3) if (is_task) {
           if (quad) task_block_quad<blk_t>(ts, e, jl_kap, jl_bet, t_rs, t_xb, t_wp, t_wr, reinterpret_cast<blk_t *>(Bt + kBT * tl));
           else {
-#if GMR_IK_MIXED
-            __builtin_trap();  // (the mixed-precision experiment covers the three-lanes-per-task path only: <= 16 tasks)
-#else
             task_block(t_body, xpos, xquat, e, jl_kap, jl_bet, t_wp, t_wr, Bt + kBT * tl);
-#endif
           }
         }
         const double diag = ik_args(Lk)->prm.damping + ik_args(Lk)->prm.lm_damping * sum_mu;
@@ -1467,20 +1423,6 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
                       // composite.  A quarter's plan entry is four source block offsets (absent ones point at the zero block) and a
                       // destination; no masks, no selects.  Same wave, so LDS program order makes a pass see the previous one's
                       // writes without a barrier.
-#if GMR_IK_MIXED
-          if (__builtin_amdgcn_inverse_ballot_w64(kmask<0x007f007fu>())) {  // (lane & 15) < 7: 28 floats of a block, four per lane
-            char *lb = reinterpret_cast<char *>(lds);
-            auto pass = [&](unsigned s0, unsigned s1, unsigned s2, unsigned s3, unsigned dst) {
-              const float4 v0 = *reinterpret_cast<const float4 *>(lb + s0), v1 = *reinterpret_cast<const float4 *>(lb + s1);
-              const float4 v2 = *reinterpret_cast<const float4 *>(lb + s2), v3 = *reinterpret_cast<const float4 *>(lb + s3);
-              float4 sum;
-              sum.x = (v0.x + v1.x) + (v2.x + v3.x);
-              sum.y = (v0.y + v1.y) + (v2.y + v3.y);
-              sum.z = (v0.z + v1.z) + (v2.z + v3.z);
-              sum.w = (v0.w + v1.w) + (v2.w + v3.w);
-              *reinterpret_cast<float4 *>(lb + dst) = sum;
-            };
-#else
           if (__builtin_amdgcn_inverse_ballot_w64(kmask<0x3fff3fffu>())) {  // (lane & 15) < kBTLanes
             char *lb = reinterpret_cast<char *>(lds);
             auto pass = [&](unsigned s0, unsigned s1, unsigned s2, unsigned s3, unsigned dst) {
@@ -1491,7 +1433,6 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
               sum.y = (v0.y + v1.y) + (v2.y + v3.y);
               *reinterpret_cast<double2 *>(lb + dst) = sum;
             };
-#endif
             // the first kCompRegs passes run from addresses resolved at the stage's entry (no plan read, no unpacking)
 #pragma unroll
             for (int p = 0; p < kCompRegs; ++p)
@@ -1506,24 +1447,6 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
         GMR_STAMP(5);
         double ci = 0.0, lo = -1e30, hi = 1e30, hdiag = 0.0;  // hdiag: S_i . F_i, the undamped diagonal of H
         GMR_DUP(6) if (real_row) {
-#if GMR_IK_MIXED
-          float B[28], Sf[6], Fi[6];  // the composite block in float32: seven 16-byte reads
-#pragma unroll
-          for (int c = 0; c < 7; c++) {
-            const float4 v = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(Bt + kBT * a_comp) + 16 * c);
-            B[4 * c] = v.x; B[4 * c + 1] = v.y; B[4 * c + 2] = v.z; B[4 * c + 3] = v.w;
-          }
-#pragma unroll
-          for (int k = 0; k < 6; k++) Sf[k] = (float)Si[k];
-          sym6_mul<float>(B, Sf, Sf + 3, Fi, Fi + 3);
-          hdiag = (double)(Sf[0] * Fi[0] + Sf[1] * Fi[1] + Sf[2] * Fi[2] + Sf[3] * Fi[3] + Sf[4] * Fi[4] + Sf[5] * Fi[5]);
-          {
-            float *Fo = reinterpret_cast<float *>(F + 6 * lane);
-#pragma unroll
-            for (int k = 0; k < 6; k++) Fo[k] = Fi[k];
-          }
-          ci = (double)(Sf[0] * B[21] + Sf[1] * B[22] + Sf[2] * B[23] + Sf[3] * B[24] + Sf[4] * B[25] + Sf[5] * B[26]);
-#else
           double B[kBTLanes * 2];  // the composite block, seven b128 reads per half
 #pragma unroll
           for (int c = 0; c < kBTLanes; c++) {
@@ -1536,7 +1459,6 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
 #pragma unroll
           for (int k = 0; k < 6; k++) F[6 * lane + k] = Fi[k];
           ci = Si[0] * B[21] + Si[1] * B[22] + Si[2] * B[23] + Si[3] * B[24] + Si[4] * B[25] + Si[5] * B[26];
-#endif
           if (!SQ && a_lim) {  // mink ConfigurationLimit: -gain (q - lower) <= dq <= gain (upper - q)
             const double qv = q[a_qadr];
             const int ar = launder(2 * lane);
@@ -1555,21 +1477,6 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
           // times over.  Plans of up to kHPlanRegs rounds (G1: 5) sit in registers for the whole work item; longer ones are read
           // from their LDS copy, one iteration ahead.
           char *lb = reinterpret_cast<char *>(lds);
-#if GMR_IK_MIXED
-          auto two_rounds = [&](const uint2 ca, const uint2 cb) {  // S_j and F_i: six floats each (16 + 8 bytes) from the same slots
-            const char *Sa = lb + (ca.x & 0xffffu), *Fa = lb + (ca.x >> 16), *Sb = lb + (cb.x & 0xffffu), *Fb = lb + (cb.x >> 16);
-            const float4 a0 = *reinterpret_cast<const float4 *>(Sa), f0 = *reinterpret_cast<const float4 *>(Fa);
-            const float2 a1 = *reinterpret_cast<const float2 *>(Sa + 16), f1 = *reinterpret_cast<const float2 *>(Fa + 16);
-            const float4 b0 = *reinterpret_cast<const float4 *>(Sb), g0 = *reinterpret_cast<const float4 *>(Fb);
-            const float2 b1 = *reinterpret_cast<const float2 *>(Sb + 16), g1 = *reinterpret_cast<const float2 *>(Fb + 16);
-            const double da = (double)(a0.x * f0.x + a0.y * f0.y + a0.z * f0.z + a0.w * f0.w + a1.x * f1.x + a1.y * f1.y);
-            const double db = (double)(b0.x * g0.x + b0.y * g0.y + b0.z * g0.z + b0.w * g0.w + b1.x * g1.x + b1.y * g1.y);
-            *reinterpret_cast<double *>(lb + (ca.y & 0xffffu)) = da;
-            *reinterpret_cast<double *>(lb + (ca.y >> 16)) = da;
-            *reinterpret_cast<double *>(lb + (cb.y & 0xffffu)) = db;
-            *reinterpret_cast<double *>(lb + (cb.y >> 16)) = db;
-          };
-#else
           auto two_rounds = [&](const uint2 ca, const uint2 cb) {
             const double2 *Sa = reinterpret_cast<const double2 *>(lb + (ca.x & 0xffffu)), *Fa = reinterpret_cast<const double2 *>(lb + (ca.x >> 16));
             const double2 *Sb = reinterpret_cast<const double2 *>(lb + (cb.x & 0xffffu)), *Fb = reinterpret_cast<const double2 *>(lb + (cb.x >> 16));
@@ -1582,7 +1489,6 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
             *reinterpret_cast<double *>(lb + (cb.y & 0xffffu)) = db;
             *reinterpret_cast<double *>(lb + (cb.y >> 16)) = db;
           };
-#endif
           if (kHPlanRegs > 0 && npairp <= 64 * kHPlanRegs) {  // wave-uniform
 #pragma unroll
             for (int it = 0; it < kHPlanRegs / 2; ++it)
@@ -1618,9 +1524,7 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
           const double lgain = ik_args(Lk)->prm.limit_gain;
           const double s_lo = fmax(-lgain * (qv - sq_rlo), -1e30), s_hi = fmin(lgain * (sq_rhi - qv), 1e30);
           double xs;
-#ifdef GMR_DUP_PHASE
-          if (GMR_DUP_PHASE == 8) { int st2 = sq_status; double x2; (void)box_qp_struct(lane, m.sq_nlimb, sq_own, sq_pad, Hm, s_ci, s_lo, s_hi, st2, x2); asm volatile("" :: "v"(x2)); }
-#endif
+          GMR_DUP_QP_TWICE();
           qit = box_qp_struct(lane, m.sq_nlimb, sq_own, sq_pad, Hm, s_ci, s_lo, s_hi, sq_status, xs);
           const double x_back = __shfl(xs, sq_owner_lane);
           dq = real_row ? x_back : 0.0;
@@ -1636,10 +1540,7 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
         }
         if (qit < 0) qpflag = 1;
         GMR_STAMP(8);
-#ifdef GMR_IK_STAMPS
-        stamp_acc[15] += (u64)(qit < 0 ? -qit : qit);  // QP iterations (not cycles)
-        if constexpr (SQ) stamp_acc[14] += __ballot(sq_own && sq_status != 0) ? 1 : 0;  // solves that end with a non-empty working set
-#endif
+        GMR_STAMP_QP();
         // ---- integrate (mj_integratePos): translations and hinges here, the root rotation inside the FK that follows ----
         const double wx = rdlane(dq, 3), wy = rdlane(dq, 4), wz = rdlane(dq, 5);
         if (real_row) {
@@ -1649,22 +1550,8 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
         __syncthreads();
         GMR_STAMP(9);
         ++solves;
-#ifdef GMR_EXP_READLANE  // experiment: what N extra SGPR-spill-style reloads per solve cost (tools/build_variant.sh)
-        {
-          int vv = (int)lane;
-#pragma unroll
-          for (int r = 0; r < GMR_EXP_READLANE; r++) {
-            int ss;
-            asm volatile("v_readlane_b32 %0, %1, 5\n\ts_nop 0" : "=s"(ss) : "v"(vv));
-          }
-        }
-#endif
-#ifdef GMR_DUP_PHASE
         fk_phase<GMR_IK_STAGE_TREE != 0, true, true>(m, bodyc, nbody, fkrounds, lane, q, xpos, xquat, wx, wy, wz, &fkj);
-        if (launder(GMR_DUP_PHASE == 1 ? 1 : 0)) fk_phase<GMR_IK_STAGE_TREE != 0>(m, bodyc, nbody, fkrounds, lane, q, xpos, xquat);
-#else
-        fk_phase<GMR_IK_STAGE_TREE != 0, true, true>(m, bodyc, nbody, fkrounds, lane, q, xpos, xquat, wx, wy, wz, &fkj);
-#endif
+        GMR_DUP_FK_TWICE();
         GMR_STAMP(1);
         double next = 0.0;
         GMR_DUP(2) {
@@ -1715,10 +1602,7 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
     if (w.check_stride == 0 && w.final_row >= 0 && qfin)
       for (int i = lane; i < nq; i += 64) qfin[(size_t)w.final_row * nq + i] = q[i];
   }
-#ifdef GMR_IK_STAMPS
-  if (lane == 0 && Lk->dbg)
-    for (int i = 0; i < 16; i++) atomicAdd(Lk->dbg + i, stamp_acc[i]);
-#endif
+  GMR_STAMP_FLUSH();
 }
 
 // One model per launch: the launch arguments are the kernel's own (IkLaunch is the second kernel argument, offset 8 behind the

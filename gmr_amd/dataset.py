@@ -28,7 +28,11 @@ from .motion_retarget import GeneralMotionRetargeting
 
 def motions_from_qpos(gmr: GeneralMotionRetargeting, qpos: torch.Tensor, seq_offsets: Sequence[int], fps,
                       height_adjust: bool = True, root_origin_offset: bool = True, ground_offset: float = 0.0) -> List[Dict]:
-    """qpos ``[N, nq]`` float64 on the GPU (concatenated clips) -> one motion dict per clip."""
+    """qpos ``[N, nq]`` float64 on the GPU (concatenated clips) -> one motion dict per clip.
+
+    The arrays of the returned dicts are row slices of four batch-sized PAGE-LOCKED host arrays (no per-clip copy): any surviving
+    motion dict keeps its whole batch pinned -- gigabytes for a dataset-sized batch.  Write the clips (``MotionWriter``) and drop
+    them, or ``copy()`` the arrays of a clip that has to outlive its batch."""
     if gmr.model.planar_base:
         # the dataset scripts read a free-joint root out of qpos (root_pos = qpos[:3], root_rot = qpos[3:7],
         # scripts/smplx_to_robot_dataset.py:97-103); the reference has no such path for galaxea_r1pro either

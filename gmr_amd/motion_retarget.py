@@ -302,6 +302,13 @@ class GeneralMotionRetargeting:
         first frame's root target instead of ``qpos0`` at the world origin, which avoids the reference's slow -- for clips facing
         away from ``qpos0`` sometimes never-ending -- start-up; the default reproduces the reference.
         Returns qpos ``[N, nq]`` float64 (same container kind as the input) and, optionally, solves per frame.
+
+        Memory: numpy batches of at least ``HOST_PIPELINE_MIN_FRAMES`` (2^18) frames go through the overlapped host pipeline
+        (``Engine.ik_solve_host``) and come back as a numpy view of PAGE-LOCKED memory the kernel wrote directly; it stays pinned as
+        long as the array (or any slice of it) is alive -- copy what must outlive the batch.  Planar-base robots (galaxea_r1pro,
+        qpos ``[x, y, yaw, hinges]``): the yaw is unwrapped along each clip starting from the first frame's principal value in
+        (-pi, pi]; MuJoCo's hinge coordinate accumulates from 0 instead, so for a clip that starts facing backwards the two can
+        differ by a multiple of 2 pi (same pose; no reference fixture pins either branch).
         """
         is_np = isinstance(pos, np.ndarray)
         if clip_start not in ("qpos0", "root_target"):

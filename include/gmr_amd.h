@@ -227,7 +227,8 @@ int gmr_smplx_keypoints_cols(const int32_t *parents, int n_joints, int joints_st
  *   names_out       host char[names_cap]: joint names, NUL-separated, in hierarchy order
  *   parents_out     host int32[max_joints] (-1 for the root); offsets_out host double[max_joints][3]
  *   channels_out    host int32[max_joints]: channel count of every joint
- *   order_out       host int32[3]: axis (0=x,1=y,2=z) of the first joint's last three channels, in listed order
+ *   order_out       host int32[3]: axes (0=x,1=y,2=z), in listed order, of the first joint whose rotation slice -- channels 0-2 of a
+ *                   3-channel joint, 3-5 of any other -- is all rotations (a positions-only root of the 9-channel layout is skipped)
  *   n_frames_out, frame_time_out: the MOTION header; motion_offset_out: byte offset of the first motion row in text
  * Returns the number of joints, -1 on a malformed file, -2 if max_joints / names_cap are too small.                      */
 int gmr_bvh_parse_header(const char *text, size_t len, int max_joints, char *names_out, size_t names_cap, int32_t *parents_out,
