@@ -62,8 +62,10 @@ typedef unsigned long long u64;
 #define GMR_IK_STAGE_TREE 1  // joint tree staged in LDS per wavefront; 0 = re-read from L2 (saves 3.3 KB LDS for G1)
 #endif
 #ifndef GMR_IK_WAVES_PER_SIMD
-#define GMR_IK_WAVES_PER_SIMD 2
-#endif
+#define GMR_IK_WAVES_PER_SIMD 2  // the structured variants (every registry robot): 2 wavefronts per SIMD at <= 256 registers.  The
+#endif                            // generic-QP variants ask for 1: a dense 40-64-entry row of H per lane plus the rest of the kernel does
+                                  // not fit 256 registers, and with 512 (256 VGPRs + AGPRs as their overflow) nothing goes to scratch
+                                  // memory -- 480 bytes per lane did for NVP 64 (profiles/r03_generic_qp_*)
 
 // Doubles per task / composite block: LL(6) LA(9) AA(6) g(6) = 27 used, the block sums move 28 (14 lanes x 16 bytes), and the
 // stride is 30 = 15 sixteen-byte slots, odd, so that the blocks of different composites start on different LDS slots: the F
@@ -1608,7 +1610,7 @@ __device__ __forceinline__ void ik_body(DevModelG &m, IkLaunchK *Lk, const LdsLa
 // One model per launch: the launch arguments are the kernel's own (IkLaunch is the second kernel argument, offset 8 behind the
 // model pointer in the kernarg segment).
 template <int NVP, bool SQ>
-__global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const DevModel *__restrict__ mp, IkLaunch L, LdsLayout lay) {
+__global__ void __launch_bounds__(64, SQ ? GMR_IK_WAVES_PER_SIMD : 1) ik_kernel(const DevModel *__restrict__ mp, IkLaunch L, LdsLayout lay) {
   IkLaunchK *Lk = (IkLaunchK *)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + 8);
   const int *perm = Lk->perm;  // a device-made launch order (gmr_ik_solve_ordered), else items run in array order
   const int item = perm ? __builtin_amdgcn_readfirstlane(perm[blockIdx.x]) : (int)blockIdx.x;
@@ -1619,7 +1621,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_kernel(const Dev
 // The probe in front of an ordered launch (gmr_ik_plan_order): the first frames of every item, solved for their cost only --
 // nothing is written but cost[item], the number of solves they took.
 template <int NVP, bool SQ>
-__global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_probe_kernel(const DevModel *__restrict__ mp, IkLaunch L, LdsLayout lay) {
+__global__ void __launch_bounds__(64, SQ ? GMR_IK_WAVES_PER_SIMD : 1) ik_probe_kernel(const DevModel *__restrict__ mp, IkLaunch L, LdsLayout lay) {
   IkLaunchK *Lk = (IkLaunchK *)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + 8);
   ik_body<NVP, SQ, false, true>(*(DevModelG *)mp, Lk, lay, (int)blockIdx.x);
 }
@@ -1662,7 +1664,7 @@ struct IkGroupEntry {
   int item_base, pad;  // first workgroup of this entry
 };
 template <int NVP, bool SQ>
-__global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_group_kernel(const IkGroupEntry *__restrict__ entries,
+__global__ void __launch_bounds__(64, SQ ? GMR_IK_WAVES_PER_SIMD : 1) ik_group_kernel(const IkGroupEntry *__restrict__ entries,
                                                                              const int *__restrict__ block_entry) {
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host pass only needs the kernel's stub; address-space-qualified copies do not parse there)
   // (readfirstlane: tell the compiler these are wave-uniform, so that everything derived from them stays in SGPRs)
@@ -1682,7 +1684,7 @@ __global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_group_kernel(con
 
 // The resident wavefront of a persistent session (see IkSessionBox above): entries[0] is the session's one-frame work item.
 template <int NVP, bool SQ>
-__global__ void __launch_bounds__(64, GMR_IK_WAVES_PER_SIMD) ik_session_kernel(const IkGroupEntry *__restrict__ entries, IkSessionBox *box,
+__global__ void __launch_bounds__(64, 1) ik_session_kernel(const IkGroupEntry *__restrict__ entries, IkSessionBox *box,
                                                                                unsigned long long idle_ticks, unsigned max_polls,
                                                                                unsigned max_frames, unsigned gen) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -8,7 +8,7 @@ import numpy as np, torch
 from gmr_amd import build, _native
 lib_path = os.path.join(ROOT, "gpurun_out", "libgmr_amd_stamps.so")
 os.makedirs(os.path.dirname(lib_path), exist_ok=True)
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DGMR_IK_STAMPS", f"-I{build.INCLUDE}",
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DGMR_IK_VARIANTS", "-DGMR_IK_STAMPS", f"-I{build.INCLUDE}",
                        "-Wno-unused-value", "-o", lib_path, os.path.join(build.CSRC, "api.hip")])
 build.LIB_PATH = _native.LIB_PATH = lib_path
 from gmr_amd import synth

@@ -1,6 +1,6 @@
 """Static instruction mix of one kernel between s_memtime markers (diagnostic -DGMR_IK_STAMPS build).
 
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -DGMR_IK_STAMPS -Iinclude -S --cuda-device-only -o /tmp/stamps.s gmr_amd/csrc/api.hip
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -DGMR_IK_VARIANTS -DGMR_IK_STAMPS -Iinclude -S --cuda-device-only -o /tmp/stamps.s gmr_amd/csrc/api.hip
     python tools/isa_regions.py /tmp/stamps.s 'ik_kernelILi36ELb1'
 
 Loops show up as backward branches (listed per region with their body size); straight-line counts are per pass.

@@ -19,7 +19,7 @@ NAMES = {0: "prep", 1: "fk", 2: "residual", 3: "task_block", 4: "screws", 5: "co
 
 
 def main():
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-DGMR_IK_MARKS", "-DGMR_IK_DEV_ONLY36", f"-I{ROOT}/include", "-S",
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-DGMR_IK_VARIANTS", "-DGMR_IK_MARKS", "-DGMR_IK_DEV_ONLY36", f"-I{ROOT}/include", "-S",
            "--cuda-device-only", "-o", OUT, f"{ROOT}/gmr_amd/csrc/api.hip"] + sys.argv[1:]
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
     lines = open(OUT).read().split("\n")
