@@ -14,7 +14,7 @@ a HIP device the constructor raises.
 """
 from __future__ import annotations
 
-from typing import Dict, Optional, Sequence, Tuple
+from typing import List, Dict, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -217,6 +217,13 @@ class GeneralMotionRetargeting:
 
     def _params(self, offset_to_ground: bool) -> IKParams:
         return IKParams(damping=self.damping, max_iter=self.max_iter, offset_to_ground=int(bool(offset_to_ground)))
+
+    @property
+    def ik_columns(self) -> List[str]:
+        """The human bodies this (source, robot) config consumes (``human_scale_table`` keys that carry a table-1 task,
+        motion_retarget.py:209-250), in the order the solver holds them: what ``columns=`` of the input adapters takes, so that
+        ``retarget_batch`` reads a dense ``[N, len(ik_columns), 7]`` instead of picking these columns out of 24 or 55."""
+        return list(self._cm.slot_names)
 
     def _columns(self, names: Sequence[str]) -> np.ndarray:
         key = tuple(names)

@@ -381,3 +381,39 @@ def test_bvh_folder_device_parse_equals_host_parse(golden_dir, tmp_path):
     open(bad, "wb").write(b"\n".join(t))
     with pytest.raises(ValueError, match="malformed motion block"):
         load_lafan1_files([files[0], bad], parse="device")
+
+
+def test_folder_to_pickles_pipeline_of_integration_md(golden_dir, tmp_path):
+    """INTEGRATION.md section 1, the folder loop of scripts/bvh_to_robot_dataset.py:59-151 on this engine: batches read ahead and parsed on
+    the device, only the columns the config reads, verified chunks, files written by the pool while the next batch solves; the pickles
+    are the serial path's, byte for byte, and read back through the reference's reader contract."""
+    import os
+    import pickle
+    import shutil
+    from gmr_amd import GeneralMotionRetargeting as GMR, dataset
+    from gmr_amd.bvh import iter_lafan1_batches, load_lafan1_file
+    src = os.path.join(golden_dir, "bvh_lafan_like.bvh")
+    files = []
+    for i in range(5):
+        files.append(str(tmp_path / f"clip{i}.bvh"))
+        shutil.copy(src, files[-1])
+    g = GMR(src_human="bvh", tgt_robot="unitree_g1")
+    assert g.ik_columns == list(g._cm.slot_names) and len(g.ik_columns) == 14
+    outs = [str(tmp_path / "out" / f"clip{i}.pkl") for i in range(5)]
+    k = 0
+    with dataset.MotionWriter(workers=3) as w:
+        for batch in iter_lafan1_batches(files, batch_files=2, columns=g.ik_columns):
+            motions = dataset.retarget_clips(g, batch.pos, batch.quat, batch.body_names, batch.seq_offsets, fps=30, height_adjust=False,
+                                             root_origin_offset=False, chunk=8, burn_in=8, human_heights=batch.human_heights)
+            w.submit(motions, outs[k:k + len(batch)])
+            k += len(batch)
+    assert w.written == 5 and k == 5
+    # the serial path on one file: full-width key-points, no chunks, stock pickle
+    clip = load_lafan1_file(src)
+    ref = dataset.retarget_clips(GMR(src_human="bvh", tgt_robot="unitree_g1"), clip.pos, clip.quat, clip.body_names, [0, len(clip)], fps=30,
+                                 height_adjust=False, root_origin_offset=False, human_heights=[clip.human_height])[0]
+    for o in outs:
+        d, fps, rp, rr_wxyz, dp, lb, names = dataset.load_robot_motion(o)
+        assert fps == 30 and names == g.model.body_names and np.abs(dp - ref["dof_pos"]).max() < 1e-6 and np.abs(rp - ref["root_pos"]).max() < 1e-6
+        dataset.validate_motion(d, nq=36)
+        assert open(o, "rb").read() == pickle.dumps(d)
