@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(64) smplx_keypoints_kernel(SmplSkeleton sk, co
     int64_t i1 = k, i2 = k;
     w.alpha = 0.0;
     if (resample) {
-      const double t = (double)k * step;
+      const double t = k == T_out - 1 && T_out > 1 ? (double)(T - 1) : (double)k * step;  // (np.linspace ends on `stop` exactly)
       i1 = (int64_t)floor(t);
       if (i1 > T - 1) i1 = T - 1;
       i2 = i1 + 1 < T ? i1 + 1 : T - 1;
