@@ -271,11 +271,13 @@ def load_lafan1_file(bvh_file: str, device: int = 0, columns=None) -> BvhClip:
 
 class BvhBatch:
     """Several BVH clips on the GPU as one batch: ``pos [N, B, 3]``, ``quat [N, B, 4]`` (concatenated clips), ``seq_offsets``,
-    one height estimate per clip -- the arguments ``retarget_batch(..., seq_offsets=..., human_heights=...)`` takes."""
+    one height estimate per clip -- the arguments ``retarget_batch(..., seq_offsets=..., human_heights=...)`` takes.  ``files`` are the
+    clips' files in batch order; ``skipped`` lists (file, reason) of files left out (``skip_errors=True``)."""
 
-    def __init__(self, pos, quat, names, seq_offsets, heights, frametimes, files):
+    def __init__(self, pos, quat, names, seq_offsets, heights, frametimes, files, skipped=None):
         self.pos, self.quat, self.body_names = pos, quat, names
         self.seq_offsets, self.human_heights, self.frametimes, self.files = seq_offsets, heights, frametimes, files
+        self.skipped = skipped or []
 
     def __len__(self):
         return len(self.files)
@@ -293,8 +295,9 @@ class _FileText:
     """What the host keeps of a batch of files whose MOTION blocks are parsed on the device: the files' bytes in ONE page-locked
     array (read straight into it) and each file's parsed header."""
 
-    def __init__(self, files, buf, starts, sizes, heads):
-        self.files, self.buf, self.starts, self.sizes, self.heads = files, buf, starts, sizes, heads
+    def __init__(self, files, buf, starts, sizes, heads, total, skipped=None):
+        self.files, self.buf, self.starts, self.sizes, self.heads, self.total = files, buf, starts, sizes, heads, total   # starts: per file
+        self.skipped: List[Tuple[str, str]] = skipped or []   # (file, reason) of files left out (skip_errors)
 
     def anim0(self) -> BvhAnim:
         names, parents, offsets, chan, order, fnum, frametime, moff = self.heads[0]
@@ -315,10 +318,22 @@ def _pinned_bytes(n: int, slot: int) -> torch.Tensor:
     return t
 
 
-def _read_files(files: List[str], threads: int, slot: int = 0) -> _FileText:
+def _read_files(files: List[str], threads: int, slot: int = 0, skip_errors: bool = False) -> _FileText:
     """Read the files into one pinned byte array (``readinto``: no intermediate bytes objects) and parse their HIERARCHY sections,
-    on ``threads`` host threads (file reads and the native header parser release the GIL)."""
+    on ``threads`` host threads (file reads and the native header parser release the GIL).  ``skip_errors``: a file that cannot be
+    read or whose header / layout the loader does not understand is left out and reported in ``.skipped`` -- the per-file
+    ``try / except: print; continue`` of scripts/bvh_to_robot_dataset.py:75-80 -- instead of failing the batch."""
     from concurrent.futures import ThreadPoolExecutor
+    skipped = []
+    if skip_errors:
+        ok = []
+        for f in files:
+            try:
+                os.path.getsize(f)
+                ok.append(f)
+            except OSError as ex:
+                skipped.append((f, str(ex)))
+        files = ok
     sizes = np.array([os.path.getsize(f) for f in files], dtype=np.int64)
     starts = np.concatenate([[0], np.cumsum((sizes + 63) // 64 * 64)]).astype(np.int64)  # every file on a 64-byte boundary
     buf = _pinned_bytes(int(starts[-1]) + 64, slot)
@@ -334,36 +349,62 @@ def _read_files(files: List[str], threads: int, slot: int = 0) -> _FileText:
                 if not r:
                     raise ValueError(f"{files[k]}: file shrank while it was read")
                 got += r
-        return _parse_header(view, files[k])
+        head = _parse_header(view, files[k])
+        _layout(head[0], head[3], files[k])
+        return head
 
-    with ThreadPoolExecutor(max_workers=max(1, min(threads, len(files)))) as ex:
-        heads = list(ex.map(one, range(len(files))))
-    return _FileText(files, buf, starts, sizes, heads)
+    def guarded(k):
+        try:
+            return one(k)
+        except (ValueError, NotImplementedError, OSError) as ex:
+            if not skip_errors:
+                raise
+            return ex
+
+    with ThreadPoolExecutor(max_workers=max(1, min(threads, max(1, len(files))))) as ex:
+        heads = list(ex.map(guarded, range(len(files))))
+    if skip_errors and any(isinstance(h, Exception) for h in heads):
+        # the first readable file sets the batch's skeleton; files of another skeleton are left out like broken ones
+        keep = [k for k, h in enumerate(heads) if not isinstance(h, Exception)]
+        skipped += [(files[k], str(h)) for k, h in enumerate(heads) if isinstance(h, Exception)]
+        return _FileText([files[k] for k in keep], buf, starts[:-1][keep], sizes[keep], [heads[k] for k in keep], int(starts[-1]), skipped)
+    return _FileText(files, buf, starts[:-1], sizes, heads, int(starts[-1]), skipped)
 
 
-def _rows_on_device(ft: _FileText, dev: torch.device, stats: Optional[dict] = None):
+def _rows_on_device(ft: _FileText, dev: torch.device, stats: Optional[dict] = None, skip_errors: bool = False):
     """The batch's MOTION blocks -> ``rows [N, ncol]`` float64 on the device (``gmr_bvh_parse_motion_device``): one H2D copy of the
     files as they are, three launches.  Tokens off the exact fast path are parsed by the host parser and patched in; a file whose
-    structure the device rejects goes through the host parser whole (which raises what it always raised).  Returns (a0, rows, offs)."""
+    structure the device rejects goes through the host parser whole (which raises what it always raised -- or, with ``skip_errors``,
+    has the file left out and reported).  Returns (a0, rows, offs, files, frame times, skipped)."""
     lib = _native.load()
-    files, heads = ft.files, ft.heads
+    skipped = list(ft.skipped)
+    if not ft.files:
+        raise ValueError("no readable BVH file in the batch: " + "; ".join(f"{f}: {r}" for f, r in skipped))
     a0 = ft.anim0()
     ncol = int(a0.rows.shape[1])
-    for f, h in zip(files, heads):
+    keep = []
+    for k, (f, h) in enumerate(zip(ft.files, ft.heads)):
         names, parents, offsets, chan, order, fnum, frametime, moff = h
         ch, nc = _layout(names, chan, f)
         if names != a0.bones or not np.array_equal(parents, a0.parents) or tuple(order) != tuple(a0.order) or ch != a0.channels \
                 or not np.array_equal(np.asarray(offsets, dtype=np.float64), a0.offsets):
-            raise ValueError(f"{f}: skeleton differs from {files[0]} (one batch = one skeleton)")
+            if not skip_errors:
+                raise ValueError(f"{f}: skeleton differs from {ft.files[0]} (one batch = one skeleton)")
+            skipped.append((f, f"skeleton differs from {ft.files[0]}"))
+        else:
+            keep.append(k)
+    if len(keep) != len(ft.files):
+        ft = _FileText([ft.files[k] for k in keep], ft.buf, ft.starts[keep], ft.sizes[keep], [ft.heads[k] for k in keep], ft.total)
+    files, heads = ft.files, ft.heads
     lens = np.array([h[5] for h in heads], dtype=np.int64)
     offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     N, nf = int(offs[-1]), len(files)
-    total = int(ft.starts[-1])
+    total = int(ft.total)
     text = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
     text[:total].copy_(ft.buf[:total], non_blocking=True)
     rows = torch.empty((N, ncol), dtype=torch.float64, device=dev)
-    seg_b = (ft.starts[:-1] + np.array([h[7] for h in heads], dtype=np.int64)).astype(np.int64)
-    seg_e = (ft.starts[:-1] + ft.sizes).astype(np.int64)
+    seg_b = (ft.starts + np.array([h[7] for h in heads], dtype=np.int64)).astype(np.int64)
+    seg_e = (ft.starts + ft.sizes).astype(np.int64)
     status = np.zeros(nf, dtype=np.int32)
     ntok = np.zeros(nf, dtype=np.int64)
     max_slow = 1 << 16
@@ -401,19 +442,33 @@ def _rows_on_device(ft: _FileText, dev: torch.device, stats: Optional[dict] = No
             val.append(float(out1[0]))
         if idx:
             rows.view(-1)[torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(dev)] = torch.from_numpy(np.asarray(val, dtype=np.float64)).to(dev)
+    bad = {}
     for k in sorted(redo):  # the host parser decides (and words the error for a malformed file)
         a, n, moff = int(ft.starts[k]), int(ft.sizes[k]), int(heads[k][7])
-        data = _parse_motion(host[a + moff:a + n], int(lens[k]), 9 * len(a0.bones) + 3, files[k])
-        if data.shape[1] != ncol:
-            raise ValueError(f"{files[k]}: expected {ncol} columns, found {data.shape[1]}")
+        try:
+            data = _parse_motion(host[a + moff:a + n], int(lens[k]), 9 * len(a0.bones) + 3, files[k])
+            if data.shape[1] != ncol:
+                raise ValueError(f"{files[k]}: expected {ncol} columns, found {data.shape[1]}")
+        except ValueError as ex:
+            if not skip_errors:
+                raise
+            bad[k] = str(ex)
+            continue
         rows[int(offs[k]):int(offs[k + 1])] = torch.from_numpy(data).to(dev)
     if stats is not None:
         stats.update({"text_bytes": int(ft.sizes.sum()), "numbers": int(N * ncol), "slow_tokens": ns, "files_reparsed_on_host": len(redo)})
-    return a0, rows, offs
+    frametimes = [h[6] for h in heads]
+    if bad:  # leave the broken files' rows out (rare: one device copy of the good ones)
+        good = [k for k in range(nf) if k not in bad]
+        skipped += [(files[k], bad[k]) for k in sorted(bad)]
+        rows = torch.cat([rows[int(offs[k]):int(offs[k + 1])] for k in good]) if good else rows[:0]
+        offs = np.concatenate([[0], np.cumsum(lens[good])]).astype(np.int64)
+        files, frametimes = [files[k] for k in good], [frametimes[k] for k in good]
+    return a0, rows, offs, files, frametimes, skipped
 
 
 def load_lafan1_files(bvh_files, device: int = 0, threads: int = 8, columns=None, parse: str = "device", stats: Optional[dict] = None,
-                      _slot: int = 0) -> BvhBatch:
+                      skip_errors: bool = False, _slot: int = 0) -> BvhBatch:
     """A folder's worth of BVH files -> one GPU batch (the file loop of scripts/bvh_to_robot_dataset.py:59-80, where every file
     is parsed with regexes and turned into per-frame dicts one after the other).  All files must share one skeleton (names,
     parents, offsets, Euler order, channel layout), as a dataset does; the height estimate of every clip (lafan1.py:45-69, from its
@@ -423,16 +478,20 @@ def load_lafan1_files(bvh_files, device: int = 0, threads: int = 8, columns=None
     parsed there (``gmr_bvh_parse_motion_device``: same numbers as the host parser, bit for bit; what is off its exact path is
     decided by the host parser) and ONE ``gmr_bvh_fk_rows`` launch does row slicing, degrees -> radians, Euler -> quaternion, the
     skeleton FK, Y-up -> Z-up, cm -> m and the FootMod synthesis for all clips -- the host only reads files and HIERARCHY sections.
-    ``parse="host"``: the MOTION blocks are parsed by ``gmr_bvh_parse_motion`` on ``threads`` host threads (round 2's path)."""
+    ``parse="host"``: the MOTION blocks are parsed by ``gmr_bvh_parse_motion`` on ``threads`` host threads (round 2's path).
+    ``skip_errors`` (device path): a file that cannot be read or parsed, or whose skeleton differs from the first good file's, is left
+    out and listed in ``batch.skipped`` -- the per-file ``try / except: print; continue`` of scripts/bvh_to_robot_dataset.py:75-80."""
     files = [str(f) for f in bvh_files]
     if not files:
         raise ValueError("no files")
     dev = torch.device("cuda", device)
+    skipped = []
     if parse == "device":
-        ft = _read_files(files, threads, _slot)
-        a0, rows, offs = _rows_on_device(ft, dev, stats)
-        frametimes = [h[6] for h in ft.heads]
+        ft = _read_files(files, threads, _slot, skip_errors)
+        a0, rows, offs, files, frametimes, skipped = _rows_on_device(ft, dev, stats, skip_errors)
     elif parse == "host":
+        if skip_errors:
+            raise ValueError("skip_errors needs parse='device'")
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=max(1, min(threads, len(files)))) as ex:
             anims = list(ex.map(read_bvh, files))
@@ -450,12 +509,13 @@ def load_lafan1_files(bvh_files, device: int = 0, threads: int = 8, columns=None
         raise ValueError("parse must be 'device' or 'host'")
     pos, quat, names = _device_fk(a0, rows, dev, columns)
     heights = _clip_heights(a0, rows, offs, dev, full=(pos, names) if columns is None else None)
-    return BvhBatch(pos, quat, names, offs, heights, frametimes, files)
+    return BvhBatch(pos, quat, names, offs, heights, frametimes, files, skipped)
 
 
-def iter_lafan1_batches(bvh_files, batch_files: int = 32, device: int = 0, threads: int = 8, columns=None):
+def iter_lafan1_batches(bvh_files, batch_files: int = 32, device: int = 0, threads: int = 8, columns=None, skip_errors: bool = False):
     """The folder in batches of ``batch_files`` files, read ahead: while the caller works on batch k (its ``retarget_batch`` call,
-    writing the results), a background thread reads batch k + 1's files and parses their headers into the other pinned buffer."""
+    writing the results), a background thread reads batch k + 1's files and parses their headers into the other pinned buffer.
+    ``skip_errors``: broken files are left out of their batch and listed in ``batch.skipped``; a batch without a good file is skipped."""
     from concurrent.futures import ThreadPoolExecutor
     files = [str(f) for f in bvh_files]
     groups = [files[i:i + batch_files] for i in range(0, len(files), max(1, batch_files))]
@@ -463,12 +523,16 @@ def iter_lafan1_batches(bvh_files, batch_files: int = 32, device: int = 0, threa
         return
     dev = torch.device("cuda", device)
     with ThreadPoolExecutor(max_workers=1) as bg:
-        nxt = bg.submit(_read_files, groups[0], threads, 0)
+        nxt = bg.submit(_read_files, groups[0], threads, 0, skip_errors)
         for g in range(len(groups)):
             ft = nxt.result()
             if g + 1 < len(groups):
-                nxt = bg.submit(_read_files, groups[g + 1], threads, (g + 1) & 1)
-            a0, rows, offs = _rows_on_device(ft, dev)
+                nxt = bg.submit(_read_files, groups[g + 1], threads, (g + 1) & 1, skip_errors)
+            if skip_errors and not ft.files:
+                yield BvhBatch(torch.empty((0, 0, 3), dtype=torch.float64, device=dev), torch.empty((0, 0, 4), dtype=torch.float64, device=dev), [],
+                               np.zeros(1, dtype=np.int64), [], [], [], list(ft.skipped))
+                continue
+            a0, rows, offs, files_g, frametimes, skipped = _rows_on_device(ft, dev, None, skip_errors)
             pos, quat, names = _device_fk(a0, rows, dev, columns)
             heights = _clip_heights(a0, rows, offs, dev, full=(pos, names) if columns is None else None)
-            yield BvhBatch(pos, quat, names, offs, heights, [h[6] for h in ft.heads], ft.files)
+            yield BvhBatch(pos, quat, names, offs, heights, frametimes, files_g, skipped)

@@ -417,3 +417,33 @@ def test_folder_to_pickles_pipeline_of_integration_md(golden_dir, tmp_path):
         assert fps == 30 and names == g.model.body_names and np.abs(dp - ref["dof_pos"]).max() < 1e-6 and np.abs(rp - ref["root_pos"]).max() < 1e-6
         dataset.validate_motion(d, nq=36)
         assert open(o, "rb").read() == pickle.dumps(d)
+
+
+def test_bvh_folder_skip_errors(golden_dir, tmp_path):
+    """skip_errors: the per-file try / except of scripts/bvh_to_robot_dataset.py:75-80 -- a missing file, a file that is not BVH, one of
+    another skeleton and one with a ragged motion row are left out and reported; the good clips are what they are without them."""
+    import os
+    import shutil
+    from gmr_amd.bvh import iter_lafan1_batches, load_lafan1_files
+    good = os.path.join(golden_dir, "bvh_lafan_like.bvh")
+    other = os.path.join(golden_dir, "bvh_pruned_mid_24f.bvh")
+    junk = str(tmp_path / "junk.bvh")
+    open(junk, "w").write("this is not a BVH file\n")
+    ragged = str(tmp_path / "ragged.bvh")
+    t = open(good, "rb").read().split(b"\n")
+    t[-4] = b" ".join(t[-4].split()[:-2])
+    open(ragged, "wb").write(b"\n".join(t))
+    g2 = str(tmp_path / "again.bvh")
+    shutil.copy(good, g2)
+    files = [good, str(tmp_path / "missing.bvh"), junk, other, ragged, g2]
+    with pytest.raises((ValueError, OSError)):
+        load_lafan1_files(files)
+    b = load_lafan1_files(files, skip_errors=True)
+    ref = load_lafan1_files([good, g2])
+    assert b.files == [good, g2] and sorted(f for f, _ in b.skipped) == sorted([files[1], junk, other, ragged]) and all(r for _, r in b.skipped)
+    assert torch.equal(b.pos, ref.pos) and torch.equal(b.quat, ref.quat) and np.array_equal(b.seq_offsets, ref.seq_offsets) and b.human_heights == ref.human_heights
+    # (a batch takes its skeleton from its first good file)
+    got = list(iter_lafan1_batches([good, files[1], junk, g2, other, ragged], batch_files=3, skip_errors=True))
+    assert [bb.files for bb in got] == [[good], [g2]] and sum(len(bb.skipped) for bb in got) == 4
+    only_bad = list(iter_lafan1_batches([junk, ragged], batch_files=1, skip_errors=True))
+    assert [len(bb) for bb in only_bad] == [0, 0] and len(only_bad[0].skipped) == 1
