@@ -66,6 +66,24 @@ def test_broadcast_shard_gather_world2():
     assert abs(loads[0] - loads[1]) <= max(lengths)
 
 
+def test_broadcast_shard_gather_world4():
+    """The same plumbing on four ranks (a rehearsal of more ranks than the two-rank tests: uneven clip counts per rank, a rank
+    whose share is a single clip, slabs that some ranks run out of before others)."""
+    lengths = [30, 7, 19, 11, 4, 25, 3]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 4, port, lengths, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] and r[3] for r in res)
+    assert sorted(i for r in res for i in r[2]) == list(range(len(lengths)))
+
+
 def test_gather_plan_is_per_clip_and_fast():
     """The host side of gather_rows works on clips, not rows: planning 2 x 8192 clips x 3000 frames (49 M rows) takes milliseconds,
     equal or unequal lengths; slabs cover every local clip exactly once and respect the byte bound."""
