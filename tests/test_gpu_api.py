@@ -539,6 +539,48 @@ def test_bench_two_rank_path_rehearsal():
     assert lc["ranks"] == 2 and lc["clips"] == 77 and lc["frames_per_s"] > 0 and lc["resolved_frames"] < 0.05 * lc["frames"]  # (initial headings within 1 rad: speculative starts hit the right basin)
 
 
+def test_c_abi_bvh_file_from_plain_c(golden_dir, tmp_path):
+    """examples/c_abi_bvh_file.c: one BVH file to qpos in C99 through the round-3 entry points -- gmr_bvh_parse_header on the host, the
+    MOTION block parsed on the device, gmr_bvh_fk_rows with the config's 14 columns, gmr_ik_solve -- against the Python loader
+    (reference-golden-pinned) and the oracle; a file with one 25-digit number exercises the off-path patch."""
+    import shutil
+    import subprocess
+    from gmr_amd import GeneralMotionRetargeting as GMR, _native
+    from gmr_amd.bvh import load_lafan1_file
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc on this box")
+    _native.load()
+    libdir = os.path.dirname(_native.LIB_PATH)
+    exe = tmp_path / "c_abi_bvh_file"
+    subprocess.check_call([gcc, "-std=c99", "-D__HIP_PLATFORM_AMD__", f"-I{root}/include", "-I/opt/rocm/include",
+                           os.path.join(root, "examples", "c_abi_bvh_file.c"), f"-L{libdir}", "-lgmr_amd", "-L/opt/rocm/lib", "-lamdhip64",
+                           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    g = GMR(src_human="bvh", tgt_robot="unitree_g1")
+    cm = g._cm
+    src = tmp_path / "clip.bvh"
+    txt = open(os.path.join(golden_dir, "bvh_lafan_like.bvh"), "rb").read().split(b"\n")
+    row = txt[-2].split()
+    row[10] = row[10] + b"000000000000000000"   # the same value with 25 digits: off the device's exact path
+    txt[-2] = b" ".join(row)
+    src.write_bytes(b"\n".join(txt))
+    d = tmp_path / "io"
+    d.mkdir()
+    (d / "model.blob").write_bytes(cm.blob)
+    (d / "cols.txt").write_text(f"{cm.robot.nq} {len(g.ik_columns)}\n" + "\n".join(g.ik_columns) + "\n")
+    out = subprocess.run([str(exe), str(src), str(d)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("ok:") and "1 off the exact path" in out.stdout, out.stderr[-2000:] + out.stdout[-500:]
+    clip = load_lafan1_file(str(src), columns=g.ik_columns)
+    T, B = len(clip), len(g.ik_columns)
+    kp = np.fromfile(d / "keypoints.f64", dtype="<f8").reshape(T, B, 7)
+    assert np.array_equal(kp[..., :3], clip.pos.cpu().numpy()) and np.array_equal(kp[..., 3:], clip.quat.cpu().numpy())
+    q = np.fromfile(d / "qpos.f64", dtype="<f8").reshape(T, cm.robot.nq)
+    it = np.fromfile(d / "iters.i32", dtype="<i4")
+    q_ref, it_ref, _ = Oracle(cm.blob).ik_solve(kp[..., :3].copy(), kp[..., 3:].copy(), np.arange(B, dtype=np.int32), make_items([0, T]))
+    assert np.abs(q - q_ref).max() < 1e-6 and np.array_equal(it & 0x3FFFFFFF, it_ref)
+
+
 def test_caller_access_pattern_of_fbx_to_robot():
     """The attribute accesses of scripts/fbx_to_robot.py on a retargeter: ``model.body(name).id`` into
     ``configuration.data.xpos`` (:1040-1041, 1083-1084, 1157-1158), ``tasks1/2`` as objects with ``frame_name`` and

@@ -321,11 +321,12 @@ def test_c_abi_headers_are_plain_c_and_the_c_example_links(tmp_path):
     from gmr_amd import _native
     _native.load()
     libdir = os.path.dirname(_native.LIB_PATH)
-    exe = tmp_path / "c_abi_retarget"
-    subprocess.check_call([gcc, "-std=c99", "-D__HIP_PLATFORM_AMD__", f"-I{root}/include", "-I/opt/rocm/include",
-                           os.path.join(root, "examples", "c_abi_retarget.c"), f"-L{libdir}", "-lgmr_amd", "-L/opt/rocm/lib", "-lamdhip64",
-                           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
-    assert exe.exists()
+    for name in ("c_abi_retarget", "c_abi_bvh_file"):   # (the second: the BVH file path through the round-3 entry points)
+        exe = tmp_path / name
+        subprocess.check_call([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", f"-I{root}/include", "-isystem", "/opt/rocm/include",
+                               os.path.join(root, "examples", name + ".c"), f"-L{libdir}", "-lgmr_amd", "-L/opt/rocm/lib", "-lamdhip64",
+                               f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+        assert exe.exists()
 
 
 def test_make_items_matches_the_plain_loop():
