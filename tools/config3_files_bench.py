@@ -74,9 +74,23 @@ def run(n_files=24, T=4000, threads=16, device=0, reps=3):
             return torch.cat(out), info
         t_q, (q_files, info) = timed(lambda: files_to_qpos(n_files))               # the whole folder as one batch (110 MB of text)
         t_q2, _ = timed(lambda: files_to_qpos(max(1, n_files // 2)))               # two batches, the second read while the first is solved
+        # ... and all the way to one pickle per clip (the whole loop body of scripts/bvh_to_robot_dataset.py:59-151): FK for local_body_pos,
+        # the reference's schema, files written by the pool
+        from gmr_amd import dataset
+        d3 = os.path.join(tmpd, "out")
+
+        def files_to_pickles():
+            with dataset.MotionWriter(workers=max(2, min(16, threads)), override=True) as w:
+                for batch in iter_lafan1_batches(kfiles, batch_files=n_files, threads=threads, columns=cols):
+                    motions = dataset.retarget_clips(g, batch.pos, batch.quat, batch.body_names, batch.seq_offsets, fps=30, height_adjust=False,
+                                                     root_origin_offset=False, chunk=64, burn_in=32, human_heights=batch.human_heights)
+                    w.submit(motions, [os.path.join(d3, os.path.basename(f)[:-4] + ".pkl") for f in batch.files])
+            return w.written
+        t_p, n_written = timed(files_to_pickles)
         q_direct = g.retarget_batch(pos, quat, names, seq_offsets=offs, human_heights=info["heights"], chunk=64, burn_in=32)
         res["from_files"] = {"files_to_qpos_frames_per_s": N / t_q, "seconds": t_q, "resolved_frames": int(info["resolved_frames"]), "batches": 1,
                              "two_batches_read_ahead_frames_per_s": N / t_q2,
+                             "files_to_pickles_frames_per_s": N / t_p, "pickles_written": int(n_written),
                              "max_abs_diff_vs_keypoints_in_memory": float((q_files - q_direct).abs().max().item()),
                              "note": "a folder this small is best taken as one batch (a batch's fixed costs -- two launches, the walk's 63 chunk boundaries per clip -- exceed what read-ahead hides); the files carry the key-points with 6 decimals (1e-8 m, 2e-8 rad): the difference to solving the in-memory key-points is that rounding"}
     finally:
