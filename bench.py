@@ -470,7 +470,9 @@ def main():
             st_el, _, _ = timed_steps(lambda: eng.ik_solve(pos[:n_s], quat[:n_s], sc, s_items, out=out[:n_s]), args.steps, 1)
             # few long clips (BASELINE config 3): a LAFAN1-sized set, chunks of every clip spread over all ranks
             lc = long_clip_set(cm, synth, dev, yaw0=1.0)
-            lc_el, _, (q_lc, _, lc_info) = timed_steps(lambda: lc["eng"].ik_solve_chunked_sharded(lc["pos"], lc["quat"], lc["sc"], lc["offs"], 64, 32), 2, 1)
+            from gmr_amd.schedule import auto_chunk
+            lch, lbi = auto_chunk(lc["offs"], world * 8 * torch.cuda.get_device_properties(dev).multi_processor_count)
+            lc_el, _, (q_lc, _, lc_info) = timed_steps(lambda: lc["eng"].ik_solve_chunked_sharded(lc["pos"], lc["quat"], lc["sc"], lc["offs"], lch, lbi), 2, 1)
             if rank == 0:
                 result["collectives"] = {
                     "backend": torch.distributed.get_backend(), "rccl_ranks": int(ones.item()),
@@ -481,7 +483,7 @@ def main():
                 }
                 result["strong"] = {"clips_total": S, "frames_per_step": S * T, "value": S * T * args.steps / st_el, "ms_per_step": 1e3 * st_el / args.steps}
                 result["long_clips_sharded"] = {"set": "heading_within_1rad", "clips": len(lc["offs"]) - 1, "frames": int(lc["offs"][-1]), "frames_per_s": 2 * int(lc["offs"][-1]) / lc_el,
-                                                "chunk": 64, "burn_in": 32, **{k: lc_info[k] for k in ("chunks", "resolved_frames", "resolved_chunks", "ranks")}}
+                                                "chunk": lch, "burn_in": lbi, **{k: lc_info[k] for k in ("chunks", "resolved_frames", "resolved_chunks", "ranks")}}
         except Exception as ex:  # the headline line must survive a failure of the extra legs
             if rank == 0:
                 result["multi_gpu_legs_error"] = repr(ex)
@@ -620,19 +622,22 @@ def main():
         # initial heading within 1 rad of the robot's (round 1's set) and once with any heading: there the reference algorithm
         # itself spends long stretches in history-dependent IK basins (its slow far-heading start-up), which no speculative
         # chunk start can reproduce -- the verification walk re-solves those stretches sequentially
-        result["long_clips"] = {"config": "bvh_to_g1, LAFAN1-sized: 77 clips of 2000-9000 frames, half noisy / over-reaching", "chunk": 64, "burn_in": 32}
+        from gmr_amd.schedule import auto_chunk
+        result["long_clips"] = {"config": "bvh_to_g1, LAFAN1-sized: 77 clips of 2000-9000 frames, half noisy / over-reaching"}
         for label, yaw0 in (("heading_within_1rad", 1.0), ("any_heading", float(np.pi))):
             lc = long_clip_set(cm, synth, dev, yaw0=yaw0)
             nfr = int(lc["offs"][-1])
+            ch, bi = auto_chunk(lc["offs"], 8 * torch.cuda.get_device_properties(dev).multi_processor_count)   # (round 2 used 64 / 32)
+            result["long_clips"].update({"chunk": ch, "burn_in": bi, "chunk_choice": "schedule.auto_chunk"})
             t_seq, (q_seq, it_seq, _) = timed(lambda: lc["eng"].ik_solve(lc["pos"], lc["quat"], lc["sc"], make_items(lc["offs"])), reps=2)
-            t_chk, (q_chk, it_chk, info) = timed(lambda: lc["eng"].ik_solve_chunked(lc["pos"], lc["quat"], lc["sc"], lc["offs"], chunk=64, burn_in=32), reps=3)
+            t_chk, (q_chk, it_chk, info) = timed(lambda: lc["eng"].ik_solve_chunked(lc["pos"], lc["quat"], lc["sc"], lc["offs"], chunk=ch, burn_in=bi), reps=3)
             result["long_clips"][label] = {"clips": len(lc["offs"]) - 1, "frames": nfr, "sequential_frames_per_s": nfr / t_seq,
                                            "verified_chunked_frames_per_s": nfr / t_chk, "resolved_frames": info["resolved_frames"],
                                            "max_abs_diff_vs_sequential": float((q_chk - q_seq).abs().max().item()),
                                            "frames_with_different_solve_count": int((it_chk != it_seq).sum().item())}
             if label == "any_heading":  # the opt-in departure from the reference: clips start on their root target (retarget_batch(clip_start=...))
                 from gmr_amd._native import INIT_ROOT_TARGET
-                t_rt, (q_rt, _, info_rt) = timed(lambda: lc["eng"].ik_solve_chunked(lc["pos"], lc["quat"], lc["sc"], lc["offs"], chunk=64, burn_in=32,
+                t_rt, (q_rt, _, info_rt) = timed(lambda: lc["eng"].ik_solve_chunked(lc["pos"], lc["quat"], lc["sc"], lc["offs"], chunk=ch, burn_in=bi,
                                                                                      clip_init=INIT_ROOT_TARGET), reps=3)
                 result["long_clips"]["any_heading_root_target_start"] = {
                     "verified_chunked_frames_per_s": nfr / t_rt, "resolved_frames": info_rt["resolved_frames"],

@@ -290,14 +290,15 @@ class GeneralMotionRetargeting:
         return float(self._errors()[1])
 
     # ------------------------------------------------------------------ batched API
-    def retarget_batch(self, pos, quat, body_names: Sequence[str], seq_offsets=None, chunk: int = 0, burn_in: int = 0,
+    def retarget_batch(self, pos, quat, body_names: Sequence[str], seq_offsets=None, chunk=0, burn_in: int = 0,
                        offset_to_ground: bool = False, return_iters: bool = False, verify: bool = True,
                        human_heights: Optional[Sequence[float]] = None, check: bool = True, clip_start: str = "qpos0"):
         """Retarget whole clips in one launch.
 
         pos ``[N, B, 3]`` (m), quat ``[N, B, 4]`` (wxyz), float32/float64, numpy or CUDA torch; ``body_names`` names the
         B columns; ``seq_offsets [S+1]`` delimits independent clips (default: one clip).  Every clip starts from
-        ``qpos0`` like a fresh reference object.  ``chunk > 0`` solves each clip in parallel-in-time chunks; with ``verify``
+        ``qpos0`` like a fresh reference object.  ``chunk > 0`` (or ``chunk="auto"``: chunk and burn-in chosen from the clip lengths,
+        ``schedule.auto_chunk``) solves each clip in parallel-in-time chunks; with ``verify``
         (default) chunk boundaries are checked and repaired so the result equals the sequential run to 1e-7
         (``Engine.ik_solve_chunked``); ``verify=False`` is the raw burn-in approximation (schedule.py).
         ``human_heights [S]`` gives every clip its own ``actual_human_height`` -- what the reference does by building one
@@ -323,7 +324,7 @@ class GeneralMotionRetargeting:
         from ._native import INIT_QPOS0, INIT_ROOT_TARGET
         clip_init = INIT_ROOT_TARGET if clip_start == "root_target" else INIT_QPOS0
         cols = self._columns(list(body_names))  # KeyError where the reference raises
-        if is_np and isinstance(quat, np.ndarray) and chunk == 0 and clip_init == INIT_QPOS0 and pos.ndim == 3 and pos.shape[0] >= self.HOST_PIPELINE_MIN_FRAMES \
+        if is_np and isinstance(quat, np.ndarray) and not isinstance(chunk, str) and chunk == 0 and clip_init == INIT_QPOS0 and pos.ndim == 3 and pos.shape[0] >= self.HOST_PIPELINE_MIN_FRAMES \
                 and not self.model.planar_base:
             # big host batches: two streams, copies overlapped with the kernel, pinned result (Engine.ik_solve_host)
             N = int(pos.shape[0])
@@ -358,6 +359,11 @@ class GeneralMotionRetargeting:
                 raise ValueError("human_heights must hold one height per clip")
             # ratio of the clip / ratio compiled into the model (:36-43): the per-item factor on the scale table
             hs = hh / self._cm.config.human_height_assumption / self._cm.ratio
+        if isinstance(chunk, str):
+            if chunk != "auto":
+                raise ValueError("chunk must be an integer or 'auto'")
+            from .schedule import auto_chunk
+            chunk, burn_in = auto_chunk(offs, 8 * torch.cuda.get_device_properties(self.device).multi_processor_count)
         if chunk > 0 and verify:
             out, iters, self.last_chunk_info = self._engine.ik_solve_chunked(
                 tpos, tquat, cols, offs, chunk, burn_in, params=self._params(offset_to_ground), height_scales=hs, clip_init=clip_init)

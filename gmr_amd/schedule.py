@@ -64,6 +64,23 @@ def make_items(seq_offsets: Sequence[int], chunk: int = 0, burn_in: int = 0, tra
     return items
 
 
+def auto_chunk(seq_offsets: Sequence[int], slots: int = 2048):
+    """(chunk, burn_in) for ``make_items`` / ``Engine.ik_solve_chunked`` when the caller does not choose: measured on one MI355X
+    (tools/experiments/chunk_sweep.py, ``profiles/r03_chunk_sweep.txt``).  Two regimes.  Few frames (fewer chunks than wavefront
+    slots): the launch lasts as long as ONE chunk with its burn-in, the walk as long as the chunk boundaries of the longest clip
+    take one after the other -- short chunks for short clips, ~sqrt(longest clip) / 2.  Many frames: chunks queue for slots, the launch
+    lasts as long as the work, and every burn-in frame is redundant work -- long chunks, about two per slot.  A burn-in of 24 frames
+    verified as often as 32 on every set and costs a quarter less."""
+    offs = np.asarray(seq_offsets, dtype=np.int64)
+    lens = np.diff(offs)
+    if lens.size == 0 or int(lens.max(initial=0)) == 0:
+        return 16, 24
+    n, longest = int(lens.sum()), int(lens.max())
+    c_latency = 8 * int(round(np.sqrt(longest) / 16.0))
+    c_fill = 8 * int(round(n / (2.0 * slots) / 8.0))
+    return int(min(128, max(16, c_latency, c_fill))), 24
+
+
 def plan_walks(items: np.ndarray, seq_offsets: Sequence[int], chunk: int) -> np.ndarray:
     """Verification walks for the tracked chunk items of ``make_items(..., chunk, track=True)``: one item per clip that has
     more than one chunk, running from the clip's second chunk to its end with ``check_stride = chunk`` (gmr_blob.h): it starts

@@ -436,3 +436,16 @@ def test_motion_writer_pool_is_byte_identical_to_serial_pickle(tmp_path):
         dataset.save_motions([{"fps": 30, "bad": (lambda: 0)}], [str(tmp_path / "bad.pkl")], workers=1)
     with pytest.raises(ValueError):
         dataset.save_motions(motions, paths[:2])
+
+
+def test_auto_chunk_regimes():
+    """schedule.auto_chunk: short chunks for a few short clips (the launch lasts one chunk + burn-in), long ones when chunks queue
+    for wavefront slots (every burn-in frame is redundant work); always inside [16, 128], burn-in 24; degenerate inputs."""
+    from gmr_amd.schedule import auto_chunk, make_items
+    assert auto_chunk([0, 3000]) == (24, 24) and auto_chunk(np.arange(25) * 4000) == (32, 24) and auto_chunk(np.arange(5) * 9000) == (48, 24)
+    assert auto_chunk(np.arange(78) * 5300)[0] in (96, 104) and auto_chunk(np.arange(8193) * 3000) == (128, 24)
+    assert auto_chunk([0]) == (16, 24) and auto_chunk([0, 0, 0]) == (16, 24) and auto_chunk([0, 5]) == (16, 24)
+    assert auto_chunk(np.arange(78) * 5300, slots=8 * 2048)[0] == 40      # eight GPUs: the same set no longer fills the slots
+    c, b = auto_chunk([0, 100, 100, 7000])
+    it = make_items([0, 100, 100, 7000], chunk=c, burn_in=b)
+    assert int(it["n_out"].sum()) == 7000 and int(it["n_out"].max()) <= c

@@ -67,7 +67,7 @@ def run(n_files=24, T=4000, threads=16, device=0, reps=3):
         def files_to_qpos(batch_files):
             out, info = [], {"resolved_frames": 0, "heights": []}
             for batch in iter_lafan1_batches(kfiles, batch_files=batch_files, threads=threads, columns=cols):
-                q = g.retarget_batch(batch.pos, batch.quat, batch.body_names, seq_offsets=batch.seq_offsets, human_heights=batch.human_heights, chunk=64, burn_in=32)
+                q = g.retarget_batch(batch.pos, batch.quat, batch.body_names, seq_offsets=batch.seq_offsets, human_heights=batch.human_heights, chunk="auto")
                 info["resolved_frames"] += g.last_chunk_info["resolved_frames"]
                 info["heights"] += list(batch.human_heights)
                 out.append(q)
@@ -83,11 +83,11 @@ def run(n_files=24, T=4000, threads=16, device=0, reps=3):
             with dataset.MotionWriter(workers=max(2, min(16, threads)), override=True) as w:
                 for batch in iter_lafan1_batches(kfiles, batch_files=n_files, threads=threads, columns=cols):
                     motions = dataset.retarget_clips(g, batch.pos, batch.quat, batch.body_names, batch.seq_offsets, fps=30, height_adjust=False,
-                                                     root_origin_offset=False, chunk=64, burn_in=32, human_heights=batch.human_heights)
+                                                     root_origin_offset=False, chunk="auto", human_heights=batch.human_heights)
                     w.submit(motions, [os.path.join(d3, os.path.basename(f)[:-4] + ".pkl") for f in batch.files])
             return w.written
         t_p, n_written = timed(files_to_pickles)
-        q_direct = g.retarget_batch(pos, quat, names, seq_offsets=offs, human_heights=info["heights"], chunk=64, burn_in=32)
+        q_direct = g.retarget_batch(pos, quat, names, seq_offsets=offs, human_heights=info["heights"], chunk="auto")
         res["from_files"] = {"files_to_qpos_frames_per_s": N / t_q, "seconds": t_q, "resolved_frames": int(info["resolved_frames"]), "batches": 1,
                              "two_batches_read_ahead_frames_per_s": N / t_q2,
                              "files_to_pickles_frames_per_s": N / t_p, "pickles_written": int(n_written),
