@@ -649,7 +649,7 @@ int build_device_model(gmr_model *m) {
     // fixed 16-lane groups, a lane occupying the 16-byte slot (addr / 16) mod 16; equal addresses broadcast) and the two
     // scatters are ds_write_b64 (16 contiguous lanes per group, unit (addr / 8) mod 16): entries are swapped between positions
     // while that lowers the number of extra LDS cycles (hill climbing with a fixed seed -- the plan is a pure function of the
-    // model).  Measured on G1: SQ_LDS_BANK_CONFLICT of the H phase.
+    // model).  Measured on G1: SQ_LDS_BANK_CONFLICT of the H phase (profiles/experiment_log_r01_r02.md, v11).
     {
       const int ne = (int)hplan.size() / 2, nr = ne / 64;
       static const int rgroup[64] = {0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1,

@@ -72,7 +72,7 @@ typedef unsigned long long u64;
 // phase (every dof lane reads element c of ITS composite) then has no bank conflicts (stride 28 = 14 slots: 91 extra LDS
 // cycles per solve on G1).  Stored "by column": element 3k + s, s = 0..2,
 // (Round 2's mixed-precision variant -- this assembly in float32: -0.5 % time, 5.4e-5 rad -- lives in the history up to commit d74eaa7,
-// DESIGN 10 item 7.)
+// profiles/experiment_log_r01_r02.md, round-2 item 7.)
 typedef double blk_t;
 constexpr int kBT = 30, kBTLanes = 14;
 // k: 0 LL(s,s)  1 LL(s,s+1)  2..4 LA(s,s), LA(s,s+1), LA(s,s+2)  5 AA(s,s)  6 AA(s,s+1)  7 gl_s  8 ga_s   (indices mod 3)

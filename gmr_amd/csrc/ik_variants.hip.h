@@ -8,7 +8,7 @@
 //
 // Closed experiments that used to sit in the kernel body behind more switches -- the mixed-precision assembly (GMR_IK_MIXED), the
 // SGPR-reload cost probe (GMR_EXP_READLANE), the register-broadcast Cholesky (GMR_QP_LDS_BCAST=0) -- are in the history up to commit
-// d74eaa7; their results are in DESIGN.md 5 / 10 and profiles/.
+// d74eaa7; their results are in profiles/experiment_log_r01_r02.md.
 #pragma once
 
 #ifdef GMR_IK_STAMPS
