@@ -536,6 +536,10 @@ def main():
                 del parts, h_rp, h_rr, h_d
             except Exception as ex:
                 result["fk"]["cpu_baseline"] = {"error": repr(ex)}
+        try:
+            result["fk"]["kin_ops"] = kin_ops_leg(eng, dof32[: min(nf, 8_000_000)])
+        except Exception as ex:
+            result["fk"]["kin_ops"] = {"error": repr(ex)}
         del root_pos32, root_rot32, dof32, bp_out, br_out
     if rank == 0 and world == 1 and (not args.hot_only or args.hot_adapters):
         # the two input-adapter kernels (rows f-1, f-2): HBM-bound by construction (1.9 - 8.4 KB per frame)
@@ -712,6 +716,40 @@ def main():
     barrier()
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def kin_ops_leg(eng, dof32, steps=3):
+    """The other KinematicsModel operators (kinematics_model.py:172-211) against the HBM roofline: dof_to_rot, rot_to_dof and
+    convert_local_rot_to_global over the bench's own joint angles (G1: 29 hinges, 38 bodies).  Algorithmic bytes per frame: every
+    input and output element once."""
+    import numpy as np
+    import torch
+    T, nb, nd = int(dof32.shape[0]), eng.nbody, eng.nq - 7
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for a, b in ev:
+            a.record(); fn(); b.record()
+        torch.cuda.synchronize()
+        return float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    def rec(kernel, ms, bpf):
+        gbs = bpf * T / (ms * 1e-3) / 1e9
+        return {"kernel": kernel, "frames": T, "kernel_ms": ms, "frames_per_s": T / (ms * 1e-3), "bytes_per_frame": bpf,
+                "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None}}
+    jr = torch.empty((T, nb - 1, 4), dtype=torch.float32, device=dof32.device)
+    out = {"dof_to_rot": rec("gmr::dof_to_rot_kernel", timed(lambda: eng.dof_to_rot(dof32, out=jr)), 4 * nd + 16 * (nb - 1))}
+    back = torch.empty((T, nd), dtype=torch.float32, device=dof32.device)
+    out["rot_to_dof"] = rec("gmr::rot_to_dof_kernel", timed(lambda: eng.rot_to_dof(jr, out=back)), 16 * (nb - 1) + 4 * nd)
+    out["rot_to_dof"]["round_trip_max_abs_diff_rad"] = float((back - dof32).abs().max().item())  # the bench's angles are inside the limits
+    del back
+    loc = torch.cat([torch.tensor([0.0, 0.0, 0.0, 1.0], device=dof32.device).expand(T, 1, 4), jr], 1).contiguous()
+    del jr
+    glob = torch.empty_like(loc)
+    out["local_rot_to_global"] = rec("gmr::local_to_global_kernel<8>", timed(lambda: eng.local_rot_to_global(loc, out=glob)), 32 * nb)
+    return out
 
 
 def adapters_leg(dev, bvh_frames=4_000_000, smplx_frames_out=1_000_000, steps=3, traffic=None):

@@ -14,7 +14,7 @@ from .build import LIB_PATH as _DEFAULT_LIB_PATH
 
 LIB_PATH = os.environ.get("GMR_AMD_LIB") or _DEFAULT_LIB_PATH  # override only for A/B diagnostics of variant builds
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 GMR_DTYPE_F32, GMR_DTYPE_F64 = 0, 1
 
 WORK_ITEM_DTYPE = np.dtype(
@@ -25,7 +25,7 @@ assert WORK_ITEM_DTYPE.itemsize == 40
 INIT_QPOS0, INIT_ROOT_TARGET = -1, -2
 
 EXPORTS = ["gmr_abi_version", "gmr_model_create", "gmr_model_destroy", "gmr_last_error", "gmr_model_info_get",
-           "gmr_ik_solve", "gmr_fk", "gmr_fk_min_height", "gmr_bvh_fk", "gmr_bvh_parse_header", "gmr_bvh_parse_motion", "gmr_evaluate", "gmr_smplx_keypoints", "gmr_smplx_keypoints_cols", "gmr_bvh_fk_rows", "gmr_bvh_parse_motion_device",
+           "gmr_ik_solve", "gmr_fk", "gmr_fk_shape", "gmr_dof_to_rot", "gmr_rot_to_dof", "gmr_local_rot_to_global", "gmr_fk_min_height", "gmr_bvh_fk", "gmr_bvh_parse_header", "gmr_bvh_parse_motion", "gmr_evaluate", "gmr_smplx_keypoints", "gmr_smplx_keypoints_cols", "gmr_bvh_fk_rows", "gmr_bvh_parse_motion_device",
            "gmr_session_create", "gmr_session_destroy", "gmr_session_reset", "gmr_session_step", "gmr_session_state", "gmr_session_set_persistent", "gmr_ik_plan_order", "gmr_ik_solve_ordered",
            "gmr_group_create", "gmr_group_destroy", "gmr_group_size", "gmr_group_model", "gmr_group_last_error", "gmr_group_ik_solve"]
 
@@ -100,6 +100,11 @@ def load():
                                C.POINTER(IKStats), vp]
     L.gmr_fk.restype = C.c_int
     L.gmr_fk.argtypes = [vp, vp, vp, vp, C.c_int64, vp, vp, vp]
+    L.gmr_fk_shape.restype = C.c_int
+    L.gmr_fk_shape.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int64, vp, vp, vp]
+    for f in ("gmr_dof_to_rot", "gmr_rot_to_dof", "gmr_local_rot_to_global"):
+        getattr(L, f).restype = C.c_int
+        getattr(L, f).argtypes = [vp, vp, C.c_int64, vp, vp]
     L.gmr_fk_min_height.restype = C.c_int
     L.gmr_fk_min_height.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp]
     L.gmr_group_create.restype = vp

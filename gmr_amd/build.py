@@ -18,7 +18,6 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libgmr_amd.so")
 SOURCES = ["api.hip"]
-DEPS = ["api.hip", "ik_kernel.hip.h", "fk_kernel.hip.h", "bvh_kernel.hip.h", "smplx_kernel.hip.h", "tree_chain.hip.h", "bvh_parse_kernel.hip.h", "bvh_text.h", "ik_variants.hip.h"]
 HEADERS = ["gmr_amd.h", "gmr_blob.h"]
 ARCH = "gfx950"
 
@@ -27,7 +26,7 @@ def _stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in DEPS] + [os.path.join(INCLUDE, f) for f in HEADERS]
+    deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(INCLUDE, f) for f in HEADERS]  # every file of csrc/: api.hip includes them all
     return any(os.path.getmtime(d) > t for d in deps)
 
 

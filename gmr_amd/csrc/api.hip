@@ -23,6 +23,7 @@
 #include "bvh_kernel.hip.h"
 #include "smplx_kernel.hip.h"
 #include "bvh_parse_kernel.hip.h"
+#include "kin_ops_kernel.hip.h"
 #include "bvh_text.h"
 
 using gmr::u64;
@@ -42,6 +43,7 @@ struct gmr_model {
   gmr::LdsLayout lay_eval{};
   int lds_bytes_eval = 0;
   gmr::FkTree fk{};
+  gmr::KinTables kin{};                    // dof_to_rot / rot_to_dof / local -> global (kin_ops_kernel.hip.h)
   gmr::LdsLayout lay{};
   int nvp = 0, n_act = 0, lds_bytes = 0, fk_lds_bytes = 0, fk_lds_bytes_min = 0;  // _min: the min-height mode has no output stage
   unsigned long long *dbg = nullptr;  // diagnostic builds (GMR_IK_STAMPS) only
@@ -828,6 +830,19 @@ int build_device_model(gmr_model *m) {
     for (int i = 0; i < 4; ++i) r.lrot[i] = lrot[4 * b + i];
   }
   const size_t o_fkbody = P.add(fkbody);
+  // kin_ops tables: hinge -> body, float32 limits, tree level of every body, bodies by level
+  const int ndof_k = nq - 7;
+  std::vector<int> k_dof_body(ndof_k, 0);
+  std::vector<float> k_lo(ndof_k, 0.f), k_hi(ndof_k, 0.f);
+  for (int b = 0; b < nb; ++b)
+    if (dofidx[b] >= 0 && dofidx[b] < ndof_k) { k_dof_body[dofidx[b]] = b; k_lo[dofidx[b]] = (float)range[2 * b]; k_hi[dofidx[b]] = (float)range[2 * b + 1]; }
+  std::vector<uint8_t> k_depth(nb, 0), k_order(nb, 0);
+  int k_maxd = 0;
+  for (int b = 1; b < nb; ++b) { k_depth[b] = (uint8_t)(k_depth[parent[b]] + 1); k_maxd = std::max<int>(k_maxd, k_depth[b]); }
+  std::iota(k_order.begin(), k_order.end(), (uint8_t)0);
+  std::stable_sort(k_order.begin(), k_order.end(), [&](uint8_t a, uint8_t b) { return k_depth[a] < k_depth[b]; });
+  const size_t o_kdb = P.add(k_dof_body), o_klo = P.add(k_lo), o_khi = P.add(k_hi), o_kdepth = P.add(k_depth),
+               o_korder = P.add(k_order);
 
   HIP_TRY(m, hipMalloc(&m->dev, P.buf.size()));
   m->dev_bytes = P.buf.size();
@@ -839,6 +854,9 @@ int build_device_model(gmr_model *m) {
   fk.parent = DP(int, o_parent); fk.dofidx = DP(int, o_dofidx); fk.src_slot = DP(int, o_src); fk.save_slot = DP(int, o_save);
   fk.lpos = DP(float, o_lpos); fk.lrot = DP(float, o_lrot); fk.jaxis = DP(float, o_jaxis); fk.jaxis64 = DP(double, o_jaxis64); fk.body = DP(gmr::FkBody, o_fkbody);
   fk.nbody = nb; fk.ndof = nq - 7; fk.nslots = nslots;
+  m->kin.dof_body = DP(int, o_kdb); m->kin.lim_lo = DP(float, o_klo); m->kin.lim_hi = DP(float, o_khi);
+  m->kin.depth = DP(uint8_t, o_kdepth); m->kin.order = DP(uint8_t, o_korder);
+  m->kin.max_depth = k_maxd;
   fk.dof_in_order = 1;
   for (int b = 0, prev = -1; b < nb; ++b)
     if (dofidx[b] >= 0) { if (dofidx[b] < prev) fk.dof_in_order = 0; prev = dofidx[b]; }
@@ -1410,42 +1428,111 @@ int gmr_evaluate(gmr_model *m, const double *qpos, int64_t n_frames, const void 
   return GMR_OK;
 }
 
-int gmr_fk(gmr_model *m, const float *root_pos, const float *root_rot_xyzw, const float *dof, int64_t n_frames, float *body_pos_out,
-           float *body_rot_out, void *stream) {
-  if (!m) return GMR_EINVAL;
-  m->err.clear();
-  if (!root_pos || !root_rot_xyzw || !body_pos_out || (!dof && m->h.nq > 7) || n_frames < 0) { set_err(m, "null argument / negative size"); return GMR_EINVAL; }
-  if (n_frames == 0) return GMR_OK;
-  HIP_TRY(m, hipSetDevice(m->device));
+/* One FK launch over `fk` (the model's tree, or a copy whose record table is a call's scaled one). */
+static int fk_launch(gmr_model *m, const gmr::FkTree &fk, const float *root_pos, const float *root_rot_xyzw, const float *dof, int64_t n_frames,
+                     float *body_pos_out, float *body_rot_out, void *stream) {
   const int64_t nblk = (n_frames + gmr::kFkThreads - 1) / gmr::kFkThreads;
   if (nblk > 0x7fffffff) { set_err(m, "too many frames for one launch"); return GMR_EINVAL; }
   // the rotation stage is the last LDS region: a positions-only call does not allocate it (more workgroups per CU)
   if (!body_rot_out && m->fk_pos_parts > 0) {  // positions only: one wavefront per tile, the whole tile image in LDS (fk_pos_kernel)
     const int64_t nw = (n_frames + gmr::kFkWave - 1) / gmr::kFkWave;
     if (nw > 0x7fffffff) { set_err(m, "too many frames for one launch"); return GMR_EINVAL; }
-    const int nb = m->fk.nbody;
-    auto image = [&](int parts) { return (std::max(1, m->fk.nslots) * 7 + (parts == 1 ? 3 * nb : 3 * ((nb + parts - 1) / parts))) * gmr::kFkWave * (int)sizeof(float); };
+    const int nb = fk.nbody;
+    auto image = [&](int parts) { return (std::max(1, fk.nslots) * 7 + (parts == 1 ? 3 * nb : 3 * ((nb + parts - 1) / parts))) * gmr::kFkWave * (int)sizeof(float); };
     int parts = m->fk_pos_parts;
     if (parts == 1 && image(1) > 160 * 1024) parts = 2;  // a tile image beyond the CU's LDS: two half images, else the grouped flush below
     const int lds = image(parts);
     if (lds > 160 * 1024) parts = 0;
     if (parts == 0) goto grouped;
     if (parts == 1)
-      hipLaunchKernelGGL((gmr::fk_pos_kernel<1>), dim3((unsigned)nw), dim3(gmr::kFkWave), lds, static_cast<hipStream_t>(stream), m->fk, root_pos,
+      hipLaunchKernelGGL((gmr::fk_pos_kernel<1>), dim3((unsigned)nw), dim3(gmr::kFkWave), lds, static_cast<hipStream_t>(stream), fk, root_pos,
                          root_rot_xyzw, dof, n_frames, body_pos_out);
     else
-      hipLaunchKernelGGL((gmr::fk_pos_kernel<2>), dim3((unsigned)nw), dim3(gmr::kFkWave), lds, static_cast<hipStream_t>(stream), m->fk, root_pos,
+      hipLaunchKernelGGL((gmr::fk_pos_kernel<2>), dim3((unsigned)nw), dim3(gmr::kFkWave), lds, static_cast<hipStream_t>(stream), fk, root_pos,
                          root_rot_xyzw, dof, n_frames, body_pos_out);
     HIP_TRY(m, hipGetLastError());
     return GMR_OK;
   }
 grouped : {
   const int fk_lds = body_rot_out ? m->fk_lds_bytes : m->fk_lds_bytes - gmr::kFkRotStride * gmr::kFkThreads * (int)sizeof(float);
-  hipLaunchKernelGGL((gmr::fk_kernel<0>), dim3((unsigned)nblk), dim3(gmr::kFkThreads), fk_lds, static_cast<hipStream_t>(stream), m->fk,
+  hipLaunchKernelGGL((gmr::fk_kernel<0>), dim3((unsigned)nblk), dim3(gmr::kFkThreads), fk_lds, static_cast<hipStream_t>(stream), fk,
                      root_pos, root_rot_xyzw, dof, n_frames, body_pos_out, body_rot_out, (const int64_t *)nullptr, 0, (int *)nullptr);
   HIP_TRY(m, hipGetLastError());
   return GMR_OK;
 }
+}
+
+int gmr_fk(gmr_model *m, const float *root_pos, const float *root_rot_xyzw, const float *dof, int64_t n_frames, float *body_pos_out,
+           float *body_rot_out, void *stream) {
+  return gmr_fk_shape(m, root_pos, root_rot_xyzw, dof, nullptr, 0, n_frames, body_pos_out, body_rot_out, stream);
+}
+
+int gmr_fk_shape(gmr_model *m, const float *root_pos, const float *root_rot_xyzw, const float *dof, const float *fitted_shape, int shape_width,
+                 int64_t n_frames, float *body_pos_out, float *body_rot_out, void *stream) {
+  if (!m) return GMR_EINVAL;
+  m->err.clear();
+  if (!root_pos || !root_rot_xyzw || !body_pos_out || (!dof && m->h.nq > 7) || n_frames < 0) { set_err(m, "null argument / negative size"); return GMR_EINVAL; }
+  if (fitted_shape && shape_width != 1 && shape_width != 3) { set_err(m, "fitted_shape is [nbody] (width 1) or [nbody][3] (width 3)"); return GMR_EINVAL; }
+  if (n_frames == 0) return GMR_OK;
+  HIP_TRY(m, hipSetDevice(m->device));
+  if (!fitted_shape) return fk_launch(m, m->fk, root_pos, root_rot_xyzw, dof, n_frames, body_pos_out, body_rot_out, stream);
+  // the call's own scaled copy of the body records, in stream-ordered scratch released behind the launch that reads it
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  CallScratch sc;
+  const int nb = m->fk.nbody;
+  int rc = scratch_alloc(m, sc, sizeof(gmr::FkBody) * (size_t)nb, st);
+  if (rc != GMR_OK) return rc;
+  hipLaunchKernelGGL(gmr::fk_scale_bodies_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, m->fk.body, fitted_shape, shape_width, nb, static_cast<gmr::FkBody *>(sc.p));
+  gmr::FkTree fk = m->fk;
+  fk.body = static_cast<const gmr::FkBody *>(sc.p);
+  return fk_launch(m, fk, root_pos, root_rot_xyzw, dof, n_frames, body_pos_out, body_rot_out, stream);
+}
+
+static unsigned kin_grid(int64_t items) {  // grid-stride kernels: enough workgroups of 256 to fill the chip several times over, never more than the work
+  const int64_t want = (items + gmr::kKinThreads - 1) / gmr::kKinThreads;
+  return (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, 256 * 32));
+}
+
+int gmr_dof_to_rot(gmr_model *m, const float *dof, int64_t n_frames, float *joint_rot_out, void *stream) {
+  if (!m) return GMR_EINVAL;
+  m->err.clear();
+  if (n_frames == 0 || (n_frames > 0 && m->fk.nbody < 2)) return GMR_OK;
+  if ((!dof && m->fk.ndof > 0) || !joint_rot_out || n_frames < 0) { set_err(m, "null argument / negative size"); return GMR_EINVAL; }
+  HIP_TRY(m, hipSetDevice(m->device));
+  hipLaunchKernelGGL(gmr::dof_to_rot_kernel, dim3(kin_grid(n_frames * (m->fk.nbody - 1))), dim3(gmr::kKinThreads), 0, static_cast<hipStream_t>(stream), m->fk,
+                     dof, n_frames, joint_rot_out);
+  HIP_TRY(m, hipGetLastError());
+  return GMR_OK;
+}
+
+int gmr_rot_to_dof(gmr_model *m, const float *joint_rot, int64_t n_frames, float *dof_out, void *stream) {
+  if (!m) return GMR_EINVAL;
+  m->err.clear();
+  if (n_frames == 0 || (n_frames > 0 && m->fk.ndof == 0)) return GMR_OK;
+  if (!joint_rot || !dof_out || n_frames < 0) { set_err(m, "null argument / negative size"); return GMR_EINVAL; }
+  HIP_TRY(m, hipSetDevice(m->device));
+  hipLaunchKernelGGL(gmr::rot_to_dof_kernel, dim3(kin_grid(n_frames * m->fk.ndof)), dim3(gmr::kKinThreads), 0, static_cast<hipStream_t>(stream), m->fk, m->kin,
+                     joint_rot, n_frames, dof_out);
+  HIP_TRY(m, hipGetLastError());
+  return GMR_OK;
+}
+
+int gmr_local_rot_to_global(gmr_model *m, const float *local_rot, int64_t n_frames, float *global_rot_out, void *stream) {
+  if (!m) return GMR_EINVAL;
+  m->err.clear();
+  if (n_frames == 0) return GMR_OK;
+  if (!local_rot || !global_rot_out || n_frames < 0) { set_err(m, "null argument / negative size"); return GMR_EINVAL; }
+  if (local_rot == global_rot_out) { set_err(m, "local_rot and global_rot_out must not alias"); return GMR_EINVAL; }
+  HIP_TRY(m, hipSetDevice(m->device));
+  constexpr int P = GMR_KIN_CHAIN_PASSES;
+  const int nb = m->fk.nbody, F = 64 * P / nb;
+  const int64_t n_batches = (n_frames + F - 1) / F;
+  const int lds = 2 * 64 * P * 16;
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_batches, 256 * 64));
+  hipLaunchKernelGGL((gmr::local_to_global_kernel<P>), dim3(grid), dim3(64), lds, static_cast<hipStream_t>(stream), m->fk, m->kin, local_rot, n_frames,
+                     global_rot_out);
+  HIP_TRY(m, hipGetLastError());
+  return GMR_OK;
 }
 
 int gmr_fk_min_height(gmr_model *m, const float *root_pos, const float *root_rot_xyzw, const float *dof, const int64_t *seq_offsets,

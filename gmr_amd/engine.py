@@ -370,9 +370,10 @@ class Engine:
         return (err, xp, xq, terr) if want_task_errors else (err, xp, xq)
 
     def fk(self, root_pos: torch.Tensor, root_rot_xyzw: torch.Tensor, dof: torch.Tensor, want_rot: bool = True,
-           out_pos: Optional[torch.Tensor] = None, out_rot: Optional[torch.Tensor] = None):
+           out_pos: Optional[torch.Tensor] = None, out_rot: Optional[torch.Tensor] = None, fitted_shape: Optional[torch.Tensor] = None):
         """``KinematicsModel.forward_kinematics``: body_pos [T,nbody,3] (and body_rot [T,nbody,4] xyzw), float32.  ``out_pos`` /
-        ``out_rot``: caller-owned result tensors (a fresh multi-GB allocation costs more than the kernel)."""
+        ``out_rot``: caller-owned result tensors (a fresh multi-GB allocation costs more than the kernel).  ``fitted_shape``: float32
+        [nbody] or [nbody, 3] on the device, the per-body scale of the local translations (kinematics_model.py:225)."""
         for t in (root_pos, root_rot_xyzw, dof):
             if t.device != self.device or t.dtype != torch.float32:
                 raise EngineError("fk inputs must be float32 tensors on the engine's device")
@@ -388,9 +389,42 @@ class Engine:
             return t
         bp = _out(out_pos, 3)
         br = _out(out_rot, 4) if want_rot else None
-        rc = self._lib.gmr_fk(self._h, _ptr(root_pos), _ptr(root_rot_xyzw), _ptr(dof), T, _ptr(bp), _ptr(br), self._stream())
+        if fitted_shape is None:
+            rc = self._lib.gmr_fk(self._h, _ptr(root_pos), _ptr(root_rot_xyzw), _ptr(dof), T, _ptr(bp), _ptr(br), self._stream())
+        else:
+            sh = fitted_shape
+            if sh.device != self.device or sh.dtype != torch.float32 or tuple(sh.shape) not in ((self.nbody,), (self.nbody, 1), (self.nbody, 3)):
+                raise EngineError("fitted_shape must be a float32 [nbody] or [nbody, 3] tensor on the engine's device")
+            sh = sh.contiguous()
+            rc = self._lib.gmr_fk_shape(self._h, _ptr(root_pos), _ptr(root_rot_xyzw), _ptr(dof), _ptr(sh), 3 if sh.dim() == 2 and sh.shape[1] == 3 else 1,
+                                        T, _ptr(bp), _ptr(br), self._stream())
         self._check(rc, "gmr_fk")
         return bp, br
+
+    def _kin_op(self, name: str, x: torch.Tensor, in_shape, out_shape, out: Optional[torch.Tensor]):
+        if x.device != self.device or x.dtype != torch.float32 or tuple(x.shape[1:]) != tuple(in_shape):
+            raise EngineError(f"{name}: input must be a float32 [T, {', '.join(map(str, in_shape))}] tensor on the engine's device")
+        T = int(x.shape[0])
+        x = x.contiguous()
+        if out is None:
+            out = torch.empty((T,) + tuple(out_shape), dtype=torch.float32, device=self.device)
+        elif tuple(out.shape) != (T,) + tuple(out_shape) or out.dtype != torch.float32 or out.device != self.device or not out.is_contiguous():
+            raise EngineError(f"{name}: the output tensor must be contiguous float32 [T, {', '.join(map(str, out_shape))}] on the engine's device")
+        rc = getattr(self._lib, name)(self._h, _ptr(x), T, _ptr(out), self._stream())
+        self._check(rc, name)
+        return out
+
+    def dof_to_rot(self, dof: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``KinematicsModel.dof_to_rot`` (kinematics_model.py:172-182): [T, ndof] -> [T, nbody-1, 4] xyzw."""
+        return self._kin_op("gmr_dof_to_rot", dof, (self.nq - 7,), (self.nbody - 1, 4), out)
+
+    def rot_to_dof(self, joint_rot: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``KinematicsModel.rot_to_dof`` (kinematics_model.py:184-197): [T, nbody-1, 4] -> [T, ndof], clamped to the joint limits."""
+        return self._kin_op("gmr_rot_to_dof", joint_rot, (self.nbody - 1, 4), (self.nq - 7,), out)
+
+    def local_rot_to_global(self, local_rot: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``KinematicsModel.convert_local_rot_to_global`` (kinematics_model.py:199-211): [T, nbody, 4] -> [T, nbody, 4]."""
+        return self._kin_op("gmr_local_rot_to_global", local_rot, (self.nbody, 4), (self.nbody, 4), out)
 
     def fk_min_height(self, root_pos: torch.Tensor, root_rot_xyzw: torch.Tensor, dof: torch.Tensor, seq_offsets) -> torch.Tensor:
         for t in (root_pos, root_rot_xyzw, dof):

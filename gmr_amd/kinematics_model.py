@@ -39,14 +39,38 @@ class KinematicsModel:
         self._dof_lower_limits = torch.tensor(lo, dtype=torch.float, device=self._device)
         self._dof_upper_limits = torch.tensor(hi, dtype=torch.float, device=self._device)
 
+    def _f32(self, x, *tail):
+        return torch.as_tensor(x).reshape(-1, *tail).to(self._device, torch.float32)
+
+    def dof_to_rot(self, dof):
+        """[..., num_dof] -> [..., num_joint - 1, 4] xyzw: each hinge's quaternion, the identity for bodies without one (:172-182)."""
+        lead = dof.shape[:-1]
+        return self._engine.dof_to_rot(self._f32(dof, self.num_dof)).reshape(*lead, self.num_joint - 1, 4)
+
+    def rot_to_dof(self, rot):
+        """[..., num_joint - 1, 4] -> [..., num_dof], clamped to the joint limits (:184-197)."""
+        lead = rot.shape[:-2]
+        return self._engine.rot_to_dof(self._f32(rot, self.num_joint - 1, 4)).reshape(*lead, self.num_dof)
+
+    def convert_local_rot_to_global(self, local_rot):
+        """[..., num_joint, 4] (row 0 = root rotation) -> global rotations, same shape (:199-211)."""
+        lead = local_rot.shape[:-2]
+        return self._engine.local_rot_to_global(self._f32(local_rot, self.num_joint, 4)).reshape(*lead, self.num_joint, 4)
+
     def forward_kinematics(self, root_pos, root_rot, dof_pos, fitted_shape=None):
-        if fitted_shape is not None:
-            raise NotImplementedError("fitted_shape is not supported")
+        """fitted_shape: [num_joint] or [num_joint, 3], multiplied onto every body's local translation (:225)."""
         lead = root_pos.shape[:-1]
-        rp = root_pos.reshape(-1, 3).to(self._device, torch.float32)
-        rr = root_rot.reshape(-1, 4).to(self._device, torch.float32)
-        dp = dof_pos.reshape(-1, self.num_dof).to(self._device, torch.float32)
-        bp, br = self._engine.fk(rp, rr, dp, want_rot=True)
+        rp = self._f32(root_pos, 3)
+        rr = self._f32(root_rot, 4)
+        dp = self._f32(dof_pos, self.num_dof)
+        sh = None
+        if fitted_shape is not None:
+            sh = torch.as_tensor(fitted_shape).to(self._device, torch.float32)
+            if sh.dim() == 2 and sh.shape[1] == 1:
+                sh = sh[:, 0]
+            if tuple(sh.shape) not in ((self.num_joint,), (self.num_joint, 3)):
+                raise ValueError("fitted_shape must have one scalar or one 3-vector per body")
+        bp, br = self._engine.fk(rp, rr, dp, want_rot=True, fitted_shape=sh)
         return bp.reshape(*lead, self.num_joint, 3), br.reshape(*lead, self.num_joint, 4)
 
     def get_body_idx(self, body_name):

@@ -29,8 +29,12 @@
  *   gmr_evaluate       error1() / error2() (motion_retarget.py:188-200) and configuration.data.xpos / xquat
  *                      (mink.Configuration.update = mj_kinematics) at given qpos, without solving
  *   gmr_fk             KinematicsModel.forward_kinematics (kinematics_model.py:213-246)
+ *   gmr_fk_shape       the same with `fitted_shape` (per-body scale of the local translations, kinematics_model.py:225)
  *   gmr_fk_min_height  the clip-global `torch.min(body_pos[..., 2])` of the height adjust
  *                      (scripts/smplx_to_robot_dataset.py:118-126)
+ *   gmr_dof_to_rot     KinematicsModel.dof_to_rot (kinematics_model.py:172-182; Joint.dof_to_rot :21-36)
+ *   gmr_rot_to_dof     KinematicsModel.rot_to_dof (kinematics_model.py:184-197; Joint.rot_to_dof :38-53), clamped to the joint limits
+ *   gmr_local_rot_to_global  KinematicsModel.convert_local_rot_to_global (kinematics_model.py:199-211)
  *   gmr_smplx_keypoints, gmr_smplx_keypoints_cols  the numeric part of get_smplx_data_offline_fast (general_motion_retargeting/utils/smpl.py:109-198)
  *                      after the SMPL-X body model: slerp/lerp to the target frame rate, orientation chaining
  *   gmr_bvh_parse_header the HIERARCHY section of read_bvh (general_motion_retargeting/utils/lafan_vendor/extract.py:60-139)
@@ -52,7 +56,7 @@
 extern "C" {
 #endif
 
-#define GMR_ABI_VERSION 4
+#define GMR_ABI_VERSION 5
 
 #define GMR_OK 0
 #define GMR_EINVAL (-1)    /* bad argument / blob / shape                     */
@@ -196,6 +200,26 @@ int gmr_evaluate(gmr_model *m, const double *qpos, int64_t n_frames, const void 
  *   body_pos_out device [n][nbody][3]; body_rot_out device [n][nbody][4] or NULL   */
 int gmr_fk(gmr_model *m, const float *root_pos, const float *root_rot_xyzw, const float *dof, int64_t n_frames,
            float *body_pos_out, float *body_rot_out, void *stream);
+
+/* The same with KinematicsModel.forward_kinematics' `fitted_shape`: every body's local translation is multiplied, in float32, by
+ * its row of fitted_shape before the chain.
+ *   fitted_shape device [nbody] (shape_width 1) or [nbody][3] (shape_width 3) float32, or NULL (= gmr_fk)
+ * The scaled body table is the call's own (stream-ordered scratch): concurrent calls with different shapes do not interfere. */
+int gmr_fk_shape(gmr_model *m, const float *root_pos, const float *root_rot_xyzw, const float *dof, const float *fitted_shape,
+                 int shape_width, int64_t n_frames, float *body_pos_out, float *body_rot_out, void *stream);
+
+/* The other KinematicsModel operators (float32, xyzw; hinge-or-fixed bodies as everywhere in this library; asynchronous on `stream`):
+ *   gmr_dof_to_rot           dof device [n][nq-7]             -> joint_rot_out device [n][nbody-1][4]: the hinge quaternion of body
+ *                            j+1's angle in row j, the identity for bodies without a hinge
+ *   gmr_rot_to_dof           joint_rot device [n][nbody-1][4] -> dof_out device [n][nq-7]: angle about the joint axis of each hinge's
+ *                            row (w made non-negative, 2 atan2(|xyz|, w), 0 below |xyz| = 1e-5, sign from the axis), clamped to the
+ *                            joint's range
+ *   gmr_local_rot_to_global  local_rot device [n][nbody][4]   -> global_rot_out device [n][nbody][4]: row 0 copied, every other row
+ *                            global[parent] (x) local in the reference's operation order (results equal a sequential float32
+ *                            evaluation bit for bit); the two arrays must not alias                                         */
+int gmr_dof_to_rot(gmr_model *m, const float *dof, int64_t n_frames, float *joint_rot_out, void *stream);
+int gmr_rot_to_dof(gmr_model *m, const float *joint_rot, int64_t n_frames, float *dof_out, void *stream);
+int gmr_local_rot_to_global(gmr_model *m, const float *local_rot, int64_t n_frames, float *global_rot_out, void *stream);
 
 /* Lowest body z per clip: min over frames [seq_offsets[s], seq_offsets[s+1]) and bodies of FK z.
  *   seq_offsets host [n_seq+1]; min_z_out device [n_seq] float32                    */

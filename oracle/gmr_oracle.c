@@ -744,8 +744,26 @@ static void quat_rotate_xyzw_f(const float q[4], const float v[3], float o[3]) {
   o[1] = v[1] * k + cy * w * 2.0f + q[1] * d * 2.0f;
   o[2] = v[2] * k + cz * w * 2.0f + q[2] * d * 2.0f;
 }
+/* Joint.dof_to_rot for a hinge (kinematics_model.py:21-36 -> torch_utils.axis_angle_to_quat :353-359): float32 sin / cos of the
+ * half angle, the product with the float64 axis and the renormalisation in float64 (type promotion), rounded to float32. */
+static void hinge_quat_f(const double *ax, float ang, float jq[4]) {
+  float th = ang / 2.0f;
+  double s = (double)sinf(th), cw = (double)cosf(th);
+  double q4[4] = {ax[0] * s, ax[1] * s, ax[2] * s, cw};
+  double n = sqrt(q4[0] * q4[0] + q4[1] * q4[1] + q4[2] * q4[2] + q4[3] * q4[3]);
+  if (n < 1e-9) n = 1e-9;
+  for (int i = 0; i < 4; i++) jq[i] = (float)(q4[i] / n);
+}
+/* fitted_shape (kinematics_model.py:225): local translation x shape[j] in float32; shape is [nb][3] (a per-body scalar is passed
+ * repeated three times) or NULL. */
+void oracle_fk_kin_shape(const oracle_model *m, const float *root_pos, const float *root_rot_xyzw, const float *dof, const float *shape,
+                         int64_t n_frames, float *body_pos, float *body_rot);
 void oracle_fk_kin(const oracle_model *m, const float *root_pos, const float *root_rot_xyzw, const float *dof, int64_t n_frames,
                    float *body_pos, float *body_rot) {
+  oracle_fk_kin_shape(m, root_pos, root_rot_xyzw, dof, NULL, n_frames, body_pos, body_rot);
+}
+void oracle_fk_kin_shape(const oracle_model *m, const float *root_pos, const float *root_rot_xyzw, const float *dof, const float *shape,
+                         int64_t n_frames, float *body_pos, float *body_rot) {
   int nb = m->h.nbody, ndof = m->h.nq - 7;
   for (int64_t f = 0; f < n_frames; f++) {
     float *P = body_pos + (size_t)f * nb * 3, Rtmp[4 * MAXB], *R = body_rot ? body_rot + (size_t)f * nb * 4 : Rtmp;
@@ -754,16 +772,10 @@ void oracle_fk_kin(const oracle_model *m, const float *root_pos, const float *ro
     for (int j = 1; j < nb; j++) {
       int p = m->parent[j];
       float jq[4] = {0, 0, 0, 1};
-      if (m->jnt_type[j] == GMR_JNT_HINGE) {
-        float ang = dof[(size_t)f * ndof + (m->qpos_adr[j] - 7)], th = ang / 2.0f;
-        double s = (double)sinf(th), cw = (double)cosf(th);
-        const double *ax = m->jnt_axis + 3 * j; /* unit: normalize(axis) */
-        double q4[4] = {ax[0] * s, ax[1] * s, ax[2] * s, cw};
-        double n = sqrt(q4[0] * q4[0] + q4[1] * q4[1] + q4[2] * q4[2] + q4[3] * q4[3]);
-        if (n < 1e-9) n = 1e-9;
-        for (int i = 0; i < 4; i++) jq[i] = (float)(q4[i] / n);
-      }
+      if (m->jnt_type[j] == GMR_JNT_HINGE) hinge_quat_f(m->jnt_axis + 3 * j /* unit: normalize(axis) */, dof[(size_t)f * ndof + (m->qpos_adr[j] - 7)], jq);
       float lt[3] = {(float)m->body_pos[3 * j], (float)m->body_pos[3 * j + 1], (float)m->body_pos[3 * j + 2]};
+      if (shape)
+        for (int i = 0; i < 3; i++) lt[i] = lt[i] * shape[3 * j + i];
       const double *qr = m->body_quat_raw + 4 * j;
       float lr[4] = {(float)qr[1], (float)qr[2], (float)qr[3], (float)qr[0]}, wt[3], t[4];
       quat_rotate_xyzw_f(R + 4 * p, lt, wt);
@@ -771,6 +783,51 @@ void oracle_fk_kin(const oracle_model *m, const float *root_pos, const float *ro
       quat_mul_xyzw_f(lr, jq, t);
       quat_mul_xyzw_f(R + 4 * p, t, R + 4 * j);
     }
+  }
+}
+
+/* KinematicsModel.dof_to_rot (kinematics_model.py:172-182): [T, ndof] -> [T, nb-1, 4] xyzw; bodies without a hinge get the identity. */
+void oracle_dof_to_rot(const oracle_model *m, const float *dof, int64_t n_frames, float *joint_rot) {
+  int nb = m->h.nbody, ndof = m->h.nq - 7;
+  for (int64_t f = 0; f < n_frames; f++)
+    for (int j = 1; j < nb; j++) {
+      float *o = joint_rot + ((size_t)f * (nb - 1) + (j - 1)) * 4;
+      o[0] = o[1] = o[2] = 0.0f; o[3] = 1.0f;
+      if (m->jnt_type[j] == GMR_JNT_HINGE) hinge_quat_f(m->jnt_axis + 3 * j, dof[(size_t)f * ndof + (m->qpos_adr[j] - 7)], o);
+    }
+}
+/* KinematicsModel.rot_to_dof (kinematics_model.py:184-197) with Joint.rot_to_dof :38-53 and torch_utils.quat_to_axis_angle :320-341,
+ * quat_pos :313-318: [T, nb-1, 4] -> [T, ndof], clamped to the joint limits (float32 tensors of the XML `range`). */
+void oracle_rot_to_dof(const oracle_model *m, const float *joint_rot, int64_t n_frames, float *dof) {
+  int nb = m->h.nbody, ndof = m->h.nq - 7;
+  for (int64_t f = 0; f < n_frames; f++)
+    for (int j = 1; j < nb; j++) {
+      if (m->jnt_type[j] != GMR_JNT_HINGE) continue;
+      const float *q0 = joint_rot + ((size_t)f * (nb - 1) + (j - 1)) * 4;
+      float z = q0[3] < 0.0f ? 1.0f : 0.0f, sg = 1.0f - 2.0f * z;
+      float q[4] = {sg * q0[0], sg * q0[1], sg * q0[2], sg * q0[3]};
+      float len = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+      float ang = 2.0f * atan2f(len, q[3]);
+      float ax[3] = {q[0] / len, q[1] / len, q[2] / len};
+      if (!(len > 1e-5f)) { ang = 0.0f; ax[0] = ax[1] = 0.0f; ax[2] = 1.0f; }
+      /* the reference dots with the RAW axis tensor (float64, not normalised: kinematics_model.py:133-134,47); only the sign is used */
+      const double *a = m->jnt_axis + 3 * j;
+      double dot = (double)ax[0] * a[0] + (double)ax[1] * a[1] + (double)ax[2] * a[2];
+      if (dot < 0.0) ang = -ang;
+      float lo = (float)m->jnt_range[2 * j], hi = (float)m->jnt_range[2 * j + 1];
+      ang = ang < lo ? lo : ang;
+      ang = ang > hi ? hi : ang;
+      dof[(size_t)f * ndof + (m->qpos_adr[j] - 7)] = ang;
+    }
+}
+/* KinematicsModel.convert_local_rot_to_global (kinematics_model.py:199-211): [T, nb, 4] -> [T, nb, 4], row 0 is the root rotation. */
+void oracle_local_rot_to_global(const oracle_model *m, const float *local_rot, int64_t n_frames, float *global_rot) {
+  int nb = m->h.nbody;
+  for (int64_t f = 0; f < n_frames; f++) {
+    const float *L = local_rot + (size_t)f * nb * 4;
+    float *G = global_rot + (size_t)f * nb * 4;
+    memcpy(G, L, 4 * sizeof(float));
+    for (int j = 1; j < nb; j++) quat_mul_xyzw_f(G + 4 * m->parent[j], L + 4 * j, G + 4 * j);
   }
 }
 

@@ -67,6 +67,11 @@ def lib():
         L.oracle_ik_solve.argtypes = [vp, C.POINTER(IKParams), vp, vp, C.c_int, C.c_int, ip, vp, C.c_int, dp, dp, dp, ip, ip, C.c_int]
         L.oracle_fk_kin.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int64,
                                     C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        fp = C.POINTER(C.c_float)
+        L.oracle_fk_kin_shape.argtypes = [vp, fp, fp, fp, fp, C.c_int64, fp, fp]
+        L.oracle_dof_to_rot.argtypes = [vp, fp, C.c_int64, fp]
+        L.oracle_rot_to_dof.argtypes = [vp, fp, C.c_int64, fp]
+        L.oracle_local_rot_to_global.argtypes = [vp, fp, C.c_int64, fp]
         L.oracle_stage_error.restype = C.c_double
         L.oracle_stage_error.argtypes = [vp, C.c_int, dp, dp, dp, dp]
         L.oracle_build_qp_at.argtypes = [vp, C.c_int, C.POINTER(IKParams), dp, dp, dp, dp, dp, dp, dp]
@@ -118,15 +123,36 @@ class Oracle:
         lib().oracle_fk_mj(self._h, _d(q), _d(xpos), _d(xquat))
         return xpos, xquat
 
-    def fk_kin(self, root_pos, root_rot_xyzw, dof, want_rot=True):
+    def fk_kin(self, root_pos, root_rot_xyzw, dof, want_rot=True, fitted_shape=None):
         rp = np.ascontiguousarray(root_pos, dtype=np.float32)
         rr = np.ascontiguousarray(root_rot_xyzw, dtype=np.float32)
         d = np.ascontiguousarray(dof, dtype=np.float32)
         T = rp.shape[0]
         bp = np.empty((T, self.nbody, 3), dtype=np.float32)
         br = np.empty((T, self.nbody, 4), dtype=np.float32) if want_rot else None
-        lib().oracle_fk_kin(self._h, _f(rp), _f(rr), _f(d), T, _f(bp), _f(br) if want_rot else None)
+        sh = None
+        if fitted_shape is not None:  # [nb] or [nb, 3] (kinematics_model.py:225)
+            sh = np.ascontiguousarray(np.broadcast_to(np.asarray(fitted_shape, np.float32).reshape(self.nbody, -1), (self.nbody, 3)))
+        lib().oracle_fk_kin_shape(self._h, _f(rp), _f(rr), _f(d), _f(sh) if sh is not None else None, T, _f(bp), _f(br) if want_rot else None)
         return bp, br
+
+    def dof_to_rot(self, dof):
+        d = np.ascontiguousarray(dof, dtype=np.float32)
+        out = np.empty((d.shape[0], self.nbody - 1, 4), dtype=np.float32)
+        lib().oracle_dof_to_rot(self._h, _f(d), d.shape[0], _f(out))
+        return out
+
+    def rot_to_dof(self, joint_rot):
+        r = np.ascontiguousarray(joint_rot, dtype=np.float32)
+        out = np.zeros((r.shape[0], self.nq - 7), dtype=np.float32)
+        lib().oracle_rot_to_dof(self._h, _f(r), r.shape[0], _f(out))
+        return out
+
+    def local_rot_to_global(self, local_rot):
+        r = np.ascontiguousarray(local_rot, dtype=np.float32)
+        out = np.empty_like(r)
+        lib().oracle_local_rot_to_global(self._h, _f(r), r.shape[0], _f(out))
+        return out
 
     def task_error_and_jacobian(self, qpos, body, tpos, tquat):
         q, tp, tq = _c64(qpos), _c64(tpos), _c64(tquat)

@@ -179,7 +179,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     lib = _native.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.gmr_abi_version() == _native.ABI_VERSION == 4
+    assert lib.gmr_abi_version() == _native.ABI_VERSION == 5
     assert ctypes.sizeof(_native.IKParams) == 48 and _native.WORK_ITEM_DTYPE.itemsize == 40
 
 

@@ -63,6 +63,27 @@ def test_fk_kin_matches_reference_golden_wide_inputs(robot, golden_dir):
     assert np.abs(br - g["body_rot"]).max() < 2e-6 * max(1.0, np.abs(g["body_rot"]).max())
 
 
+@pytest.mark.parametrize("robot", GOLDEN_ROBOTS)
+def test_kin_ops_match_reference_golden(robot, golden_dir):
+    """dof_to_rot / rot_to_dof / convert_local_rot_to_global / forward_kinematics(fitted_shape=) of the reference's KinematicsModel
+    (kinematics_model.py:172-246; tests/golden/make_golden_kin_ops.py) against the oracle's float32 restatements.  rot_to_dof's inputs
+    include w < 0, rotations below the 1e-5 axis threshold and rotations next to pi; the result is clamped to the joint limits."""
+    cm = compiled("smplx", robot)
+    g = np.load(os.path.join(golden_dir, f"kin_ops_{robot}.npz"))
+    orc = Oracle(cm.blob)
+    assert np.abs(orc.dof_to_rot(g["dof_pos"]) - g["joint_rot"]).max() < 2e-7
+    back = orc.rot_to_dof(g["rot_in"])
+    assert back.shape == g["dof_back"].shape
+    assert np.abs(back - g["dof_back"]).max() < 2e-6
+    lo, hi = cm.robot.dof_limits()
+    assert (back >= lo.astype(np.float32)).all() and (back <= hi.astype(np.float32)).all()
+    assert np.abs(orc.local_rot_to_global(g["local_rot"]) - g["global_rot"]).max() < 2e-6
+    for key in ("shape1", "shape3"):
+        bp, br = orc.fk_kin(g["root_pos"], g["root_rot"], g["dof_pos"], fitted_shape=g[key])
+        assert np.abs(bp - g[f"body_pos_{key}"]).max() < 2e-6 * max(1.0, np.abs(g[f"body_pos_{key}"]).max())
+        assert np.abs(br - g[f"body_rot_{key}"]).max() < 2e-6
+
+
 def test_quat_mul_convention(golden_dir):
     """wxyz Hamilton product agrees with reference rot_utils.quat_mul_np (golden)."""
     g = np.load(os.path.join(golden_dir, "quat_mul_wxyz.npz"))
