@@ -98,6 +98,10 @@ def self_launch(args) -> int:
 ADAPTER_PMC_SIZES = (2_000_000, 500_000)   # (bvh frames, smplx output frames) of the adapters leg inside the PMC child passes
 
 
+# kernels of the fk leg whose HBM traffic the PMC child passes read (substring of the kernel name -> record)
+FK_PMC_KERNELS = ("fk_pos_kernel", "fk_kernel<0", "dof_to_rot_kernel", "rot_to_dof_kernel", "local_to_global_kernel")
+
+
 def measure_traffic_pmc(frames=600, clips=8192, timeout=300, adapters=True):
     """HBM bytes from PMC counters, measured now: one child `rocprofv3 --pmc C --kernel-trace` run per counter (they do not fit one
     pass) over `bench.py --hot-only [--hot-adapters]` with short clips.  Returns (bytes_per_frame of ik_kernel, detail, adapters)
@@ -119,7 +123,7 @@ def measure_traffic_pmc(frames=600, clips=8192, timeout=300, adapters=True):
             cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
                    "--hot-only", "--steps", "1", "--warmup", "1", "--frames", str(frames), "--clips", str(clips), "--traffic", "const"]
             if adapters:
-                cmd.append("--hot-adapters")
+                cmd += ["--hot-adapters", "--hot-fk"]
             r = subprocess.run(cmd, cwd=tempfile.gettempdir(), env=dict(os.environ, TMPDIR=tempfile.gettempdir()), capture_output=True, text=True, timeout=timeout)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
@@ -133,13 +137,20 @@ def measure_traffic_pmc(frames=600, clips=8192, timeout=300, adapters=True):
             for key in ("bvh_fk_kernel", "smplx_keypoints_kernel"):
                 seq = [float(row["Counter_Value"]) for row in rows if key in row["Kernel_Name"]]
                 ad.setdefault(key, {})[counter] = seq[1::2]  # (warm-up, timed) pairs per configuration: the timed ones
+            for key in FK_PMC_KERNELS:  # the fk leg of the same child run: the last dispatch of each kernel
+                seq = [float(row["Counter_Value"]) for row in rows if key in row["Kernel_Name"]]
+                if seq:
+                    ad.setdefault("_fk", {}).setdefault(key, {})[counter] = seq[-1]
         except Exception as ex:  # timeout, parse error: fall back to the committed figure
             return None, f"{counter} pass: {ex!r}", None
         finally:
             shutil.rmtree(d, ignore_errors=True)
     n = frames * clips
     bpf = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0 / n  # gfx950 tallies 128-byte read requests at 64 bytes
+    fk_kb = ad.pop("_fk", {})
     adapters_kb = {k: list(zip(v.get("FETCH_SIZE", []), v.get("WRITE_SIZE", []))) for k, v in ad.items()} if adapters else None
+    if adapters_kb is not None:
+        adapters_kb["_fk"] = {"frames_in_pass": n, "kernels": {k: (v["FETCH_SIZE"], v["WRITE_SIZE"]) for k, v in fk_kb.items() if len(v) == 2}}
     return bpf, {"FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"], "frames_in_pass": n}, adapters_kb
 
 
@@ -540,6 +551,7 @@ def main():
             result["fk"]["kin_ops"] = kin_ops_leg(eng, dof32[: min(nf, 8_000_000)])
         except Exception as ex:
             result["fk"]["kin_ops"] = {"error": repr(ex)}
+        attach_fk_traffic(result["fk"], live_traffic[2])
         del root_pos32, root_rot32, dof32, bp_out, br_out
     if rank == 0 and world == 1 and (not args.hot_only or args.hot_adapters):
         # the two input-adapter kernels (rows f-1, f-2): HBM-bound by construction (1.9 - 8.4 KB per frame)
@@ -843,6 +855,34 @@ def adapters_leg(dev, bvh_frames=4_000_000, smplx_frames_out=1_000_000, steps=3,
         del go, fp, jt
     torch.cuda.empty_cache()
     return out
+
+
+def attach_fk_traffic(fk_rec, kb):
+    """roofline.traffic of the fk records (fk_pos_kernel, fk_kernel<0>, the kin_ops kernels) from the same PMC child passes: the last
+    dispatch of each kernel in the child's fk leg, (2 x FETCH_SIZE + WRITE_SIZE) per frame of THAT dispatch, scaled to the timed launch."""
+    info = (kb or {}).get("_fk") or {}
+    n, ks = info.get("frames_in_pass"), info.get("kernels", {})
+    if not n:
+        return
+
+    def put(roof, key, frames_in_dispatch, frames, alg):
+        if key not in ks:
+            return
+        fetch_kb, write_kb = ks[key]
+        bpf = (2.0 * fetch_kb + write_kb) * 1024.0 / frames_in_dispatch
+        roof["traffic"] = bpf * frames
+        roof["traffic_bytes_per_frame"] = bpf
+        roof["traffic_over_algorithmic"] = bpf / alg
+        roof["traffic_source"] = {"FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb, "frames_in_pass": frames_in_dispatch,
+                                  "how": "this run: rocprofv3 --pmc child passes, 2 x FETCH_SIZE + WRITE_SIZE"}
+    put(fk_rec["roofline"], "fk_pos_kernel", n, fk_rec["frames"], fk_rec["roofline"]["bytes_per_frame"])
+    wr = fk_rec.get("with_rotations")
+    if wr is not None:
+        put(wr, "fk_kernel<0", n // 2, wr["frames"], wr["bytes_per_frame"])
+    for name, key in (("dof_to_rot", "dof_to_rot_kernel"), ("rot_to_dof", "rot_to_dof_kernel"), ("local_rot_to_global", "local_to_global_kernel")):
+        r = (fk_rec.get("kin_ops") or {}).get(name)
+        if isinstance(r, dict) and "roofline" in r:
+            put(r["roofline"], key, min(n, 8_000_000), r["frames"], r["bytes_per_frame"])
 
 
 def attach_adapter_traffic(rec, kb):

@@ -45,10 +45,15 @@ __global__ void __launch_bounds__(kKinThreads) dof_to_rot_kernel(FkTree t, const
     for (int i = 0; i < 3; ++i) s_axis[3 * b + i] = t.jaxis64[3 * b + i];
   }
   __syncthreads();
-  const int64_t n = n_frames * nj, stride = (int64_t)gridDim.x * kKinThreads;
-  for (int64_t i = (int64_t)blockIdx.x * kKinThreads + threadIdx.x; i < n; i += stride) {
-    const int64_t f = i / nj;
-    const int j = 1 + (int)(i - f * nj);
+  // (frame, joint) of this thread's items by increments: one 64-bit division per thread instead of one per item
+  const int64_t n = n_frames * nj, stride = (int64_t)gridDim.x * kKinThreads, i0 = (int64_t)blockIdx.x * kKinThreads + threadIdx.x;
+  const int64_t sf = stride / nj;
+  const int sj = (int)(stride - sf * nj);
+  int64_t f = i0 / nj;
+  int jj = (int)(i0 - f * nj);
+  for (int64_t i = i0; i < n; i += stride, f += sf, jj += sj) {
+    if (jj >= nj) { jj -= nj; ++f; }
+    const int j = 1 + jj;
     const int d = s_dof[j];
     float q[4] = {0.f, 0.f, 0.f, 1.f};
     if (d >= 0) {
@@ -75,10 +80,13 @@ __global__ void __launch_bounds__(kKinThreads) rot_to_dof_kernel(FkTree t, KinTa
     for (int i = 0; i < 3; ++i) s_axis[3 * d + i] = t.jaxis64[3 * b + i];
   }
   __syncthreads();
-  const int64_t n = n_frames * ndof, stride = (int64_t)gridDim.x * kKinThreads;
-  for (int64_t i = (int64_t)blockIdx.x * kKinThreads + threadIdx.x; i < n; i += stride) {
-    const int64_t f = i / ndof;
-    const int d = (int)(i - f * ndof);
+  const int64_t n = n_frames * ndof, stride = (int64_t)gridDim.x * kKinThreads, i0 = (int64_t)blockIdx.x * kKinThreads + threadIdx.x;
+  const int64_t sf = stride / ndof;
+  const int sd = (int)(stride - sf * ndof);
+  int64_t f = i0 / ndof;
+  int d = (int)(i0 - f * ndof);
+  for (int64_t i = i0; i < n; i += stride, f += sf, d += sd) {
+    if (d >= ndof) { d -= ndof; ++f; }
     const float4 q0 = reinterpret_cast<const float4 *>(rot)[f * nj + (s_body[d] - 1)];
     const float sg = 1.0f - 2.0f * (q0.w < 0.0f ? 1.0f : 0.0f);
     const float x = sg * q0.x, y = sg * q0.y, z = sg * q0.z, w = sg * q0.w;
