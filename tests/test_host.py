@@ -449,3 +449,14 @@ def test_auto_chunk_regimes():
     c, b = auto_chunk([0, 100, 100, 7000])
     it = make_items([0, 100, 100, 7000], chunk=c, burn_in=b)
     assert int(it["n_out"].sum()) == 7000 and int(it["n_out"].max()) <= c
+
+
+def test_bvh_text_entry_points_survive_hostile_input():
+    """gmr_bvh_parse_header / gmr_bvh_parse_motion (host code of the library) on mutated files: text that ends at a PROT_NONE page,
+    outputs between canaries, capacities around the joint count (tools/fuzz_bvh_text.py; 1.3 M calls in profiles/r03_fuzz_bvh_text.txt)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_bvh_text.py"), "3", "5"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 violations" in r.stdout
