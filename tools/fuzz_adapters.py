@@ -8,6 +8,7 @@ Random skeletons (1-192 joints: every lane layout), all three BVH row layouts, E
 batch / run edges, column selections; SMPL-X trees of 2-64 joints with and without resampling, small and large frame-to-frame rotations;
 MOTION text with random number formats, separators, line endings, blank lines and segment offsets.  Prints one summary line per family.
 """
+import ctypes as C
 import os
 import sys
 import time
@@ -109,10 +110,55 @@ def main():
         assert got.tobytes() == exp.tobytes()
         s = stats["text"]
         s[0] += 1; s[1] += n_lines * n_cols; s[2] += int(ns); s[3] += len(text)
+        # ---- hostile text: mutated / random bytes.  The device parser must never guess: whenever the host parser accepts the block
+        # (n_lines rows of n_cols numbers), the device's values, with its reported tokens patched by float(), are the host's bit for bit;
+        # whatever the host rejects the device flags (status) or hands over (slow list) -- and nothing faults.
+        h = stats.setdefault("hostile", [0, 0, 0, 0])
+        for _ in range(4):
+            n_cols = int(rng.integers(1, 12)); n_lines = int(rng.integers(1, 40))
+            base = "\n".join(" ".join("%.6f" % v for v in rng.normal(0, 30, n_cols)) for _ in range(n_lines)).encode() + b"\n"
+            b2 = bytearray(base)
+            kind = int(rng.integers(0, 5))
+            if kind == 0:
+                b2 = b2[: int(rng.integers(0, len(b2) + 1))]
+            elif kind == 1:
+                for _k in range(int(rng.integers(1, 6))):
+                    b2[int(rng.integers(0, len(b2)))] = int(rng.integers(0, 256))
+            elif kind == 2:
+                alphabet = b"0123456789.eE+- \t\r\n" + bytes([0, 255, ord("x"), ord("n"), ord("a")])
+                b2 = bytearray(alphabet[int(i)] for i in rng.integers(0, len(alphabet), int(rng.integers(1, 9000))))
+            elif kind == 3:
+                toks = bytes(b2).split()
+                toks[int(rng.integers(0, len(toks)))] = [b"1e999", b"9" * 40, b"1e", b"-", b".", b"nan", b"inf", b"0x10", b"1e-400", b"0." + b"0" * 60 + b"7", b"+.5e+2"][int(rng.integers(0, 11))]
+                b2 = bytearray(b" ".join(toks))
+            text = bytes(b2)
+            if not text:
+                continue
+            junk = b"#" * int(rng.integers(0, 70))
+            blob = junk + text
+            rc, rows_d, status, ntok, slow, ns = T._device_parse(lib, dev, blob, [(len(junk), len(junk) + len(text))], [n_lines], n_cols, max_slow=1 << 14)
+            assert rc == 0, rc
+            hout = np.full(n_lines * n_cols + 8, np.nan)
+            nl_h, nc_h = C.c_int64(0), C.c_int64(0)
+            got_h = lib.gmr_bvh_parse_motion(text, len(text), n_lines, hout.ctypes.data_as(vp), n_lines * n_cols, C.byref(nl_h), C.byref(nc_h))
+            h[0] += 1
+            if got_h == n_lines * n_cols and nc_h.value == n_cols:
+                h[1] += 1
+                assert status[0] == 0 and ns == len(slow), (status, ns, text[:80])
+                got = rows_d.copy().reshape(-1)
+                for k, t, b in slow:
+                    got[int(t)] = float(blob[int(b):].split()[0])
+                assert got.tobytes() == hout[: n_lines * n_cols].tobytes(), text[:120]
+            else:
+                h[2] += int(status[0] != 0 or ns > 0 or int(ntok[0]) < n_lines * n_cols)
+                h[3] += 1
     b, sx, tx = stats["bvh"], stats["smplx"], stats["text"]
     print(f"seed {seed}, {budget:.0f} s")
     print(f"bvh_fk_kernel:           {b[0]} batches, {b[1]} frames: worst |pos - restatement| (relative) {b[2]:.2e}, worst |quat - restatement| {b[3]:.2e}; column selections bitwise equal")
     print(f"smplx_keypoints_kernel:  {sx[0]} batches, {sx[1]} output frames: worst |pos| {sx[2]:.2e}, worst |quat| (up to sign) {sx[3]:.2e}")
+    hs = stats.get("hostile", [0, 0, 0, 0])
+    print(f"hostile text:            {hs[0]} blocks of truncated / flipped / random bytes: {hs[1]} accepted by the host parser -> device values identical; "
+          f"{hs[3]} rejected by the host parser -> {hs[2]} of them flagged or handed over by the device")
     print(f"bvh_txt_parse_kernel:    {tx[0]} blocks, {tx[1]} numbers, {tx[3]} bytes: every number == float(token) bit for bit ({tx[2]} handed to the host as off the exact path)")
 
 
