@@ -134,7 +134,7 @@ def measure_traffic_pmc(frames=600, clips=8192, timeout=300, adapters=True):
             if not got:
                 return None, f"no ik_kernel rows in the {counter} pass", None
             vals[counter] = got[-1]  # the timed launch (the last dispatch); KB
-            for key in ("bvh_fk_kernel", "smplx_keypoints_kernel"):
+            for key in ("bvh_fk_kernel", "smplx_keypoints_kernel<double>"):
                 seq = [float(row["Counter_Value"]) for row in rows if key in row["Kernel_Name"]]
                 ad.setdefault(key, {})[counter] = seq[1::2]  # (warm-up, timed) pairs per configuration: the timed ones
             for key in FK_PMC_KERNELS:  # the fk leg of the same child run: the last dispatch of each kernel
@@ -669,6 +669,14 @@ def main():
                                                   "loader_only": {"text_MB": ff["text_MB"], **ff["loader"]}}
         except Exception as ex:
             result["long_clips"]["from_files"] = {"error": repr(ex)}
+        # the SMPL-X side of the file path (scripts/smplx_to_robot_dataset.py:63-146 behind the body model): a folder of joint-array files
+        # -> adapter -> IK with one height per file -> FK / post-processing -> pickles (tools/smplx_files_bench.py)
+        try:
+            import smplx_files_bench
+            result["dataset_path"]["from_joint_files"] = smplx_files_bench.run(1024, 750, max(2, min(16, host_cores())), dev.index, batch_files=512)
+        except Exception as ex:
+            if isinstance(result.get("dataset_path"), dict):
+                result["dataset_path"]["from_joint_files"] = {"error": repr(ex)}
         # BASELINE config 4: five robots' batches (5 x 64 clips x 1000 frames) as ONE launch (gmr_group_*) and as five launches on
         # five streams (round 1's form)
         try:
@@ -826,6 +834,7 @@ def adapters_leg(dev, bvh_frames=4_000_000, smplx_frames_out=1_000_000, steps=3,
         T_out = smplx_frames_out
         T = T_out * skip
         go, fp, jt = synth.smplx_arrays_torch(T, dev, Jx, S)
+        go32 = fp32 = jt32 = None
         for label, cols in (("all_columns", None), ("ik_columns", np.array([SMPLX_JOINT_NAMES.index(c) for c in live_cols], np.int32))):
             B = Jx if cols is None else len(cols)
             if cols is None:
@@ -847,12 +856,25 @@ def adapters_leg(dev, bvh_frames=4_000_000, smplx_frames_out=1_000_000, steps=3,
                 assert rc == 0, rc
             ms = timed(run)
             src_rows = 2 if skip > 1 else 1
-            out.setdefault("smplx", {}).setdefault(mode, {})[label] = record(
-                "gmr::smplx_keypoints_kernel", T_out, ms, src_rows * (n_rot + n_pos) * 24, B * 56,
+            rec = record(
+                "gmr::smplx_keypoints_kernel<double>", T_out, ms, src_rows * (n_rot + n_pos) * 24, B * 56,
                 f"AMASS-shaped: 55 joints of a 127-joint position array, {'two source frames per output frame (slerp / lerp)' if skip > 1 else 'one source frame per output frame'}, "
                 f"{n_rot} rotations + {n_pos} positions read, {B} output columns")
+            # the same arrays as float32 (a body model's own dtype; gmr_smplx_keypoints_in promotes on load): half the input bytes
+            if go32 is None:
+                go32, fp32, jt32 = go.float(), fp.float(), jt.float()
+
+            def run32():
+                rc = lib.gmr_smplx_keypoints_in(par.ctypes.data_as(vp), Jx, S, vp(go32.data_ptr()), vp(fp32.data_ptr()), vp(jt32.data_ptr()), 0, T, T_out, int(skip > 1),
+                                                cols.ctypes.data_as(vp) if cols is not None else None, B, vp(pos.data_ptr()), vp(quat.data_ptr()), st)
+                assert rc == 0, rc
+            ms32 = timed(run32)
+            b32 = src_rows * (n_rot + n_pos) * 12 + B * 56
+            rec["float32_input"] = {"kernel": "gmr::smplx_keypoints_kernel<float>", "kernel_ms": ms32, "frames_per_s": T_out / (ms32 * 1e-3), "bytes_per_frame": b32,
+                                    "frac": b32 * T_out / (ms32 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            out.setdefault("smplx", {}).setdefault(mode, {})[label] = rec
             del pos, quat
-        del go, fp, jt
+        del go, fp, jt, go32, fp32, jt32
     torch.cuda.empty_cache()
     return out
 
@@ -891,7 +913,7 @@ def attach_adapter_traffic(rec, kb):
     if not kb:
         return
     order = [("bvh_fk_kernel", [rec["bvh"]["all_columns"], rec["bvh"]["ik_columns"]], ADAPTER_PMC_SIZES[0]),
-             ("smplx_keypoints_kernel", [rec["smplx"][m][c] for m in ("resample_120_to_30", "one_to_one") for c in ("all_columns", "ik_columns")], ADAPTER_PMC_SIZES[1])]
+             ("smplx_keypoints_kernel<double>", [rec["smplx"][m][c] for m in ("resample_120_to_30", "one_to_one") for c in ("all_columns", "ik_columns")], ADAPTER_PMC_SIZES[1])]
     for key, recs, frames_in_pass in order:
         seq = kb.get(key) or []
         if len(seq) != len(recs):

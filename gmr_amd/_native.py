@@ -25,7 +25,7 @@ assert WORK_ITEM_DTYPE.itemsize == 40
 INIT_QPOS0, INIT_ROOT_TARGET = -1, -2
 
 EXPORTS = ["gmr_abi_version", "gmr_model_create", "gmr_model_destroy", "gmr_last_error", "gmr_model_info_get",
-           "gmr_ik_solve", "gmr_fk", "gmr_fk_shape", "gmr_dof_to_rot", "gmr_rot_to_dof", "gmr_local_rot_to_global", "gmr_fk_min_height", "gmr_bvh_fk", "gmr_bvh_parse_header", "gmr_bvh_parse_motion", "gmr_evaluate", "gmr_smplx_keypoints", "gmr_smplx_keypoints_cols", "gmr_bvh_fk_rows", "gmr_bvh_parse_motion_device",
+           "gmr_ik_solve", "gmr_fk", "gmr_fk_shape", "gmr_dof_to_rot", "gmr_rot_to_dof", "gmr_local_rot_to_global", "gmr_fk_min_height", "gmr_bvh_fk", "gmr_bvh_parse_header", "gmr_bvh_parse_motion", "gmr_evaluate", "gmr_smplx_keypoints", "gmr_smplx_keypoints_cols", "gmr_smplx_keypoints_in", "gmr_bvh_fk_rows", "gmr_bvh_parse_motion_device",
            "gmr_session_create", "gmr_session_destroy", "gmr_session_reset", "gmr_session_step", "gmr_session_state", "gmr_session_set_persistent", "gmr_ik_plan_order", "gmr_ik_solve_ordered",
            "gmr_group_create", "gmr_group_destroy", "gmr_group_size", "gmr_group_model", "gmr_group_last_error", "gmr_group_ik_solve"]
 
@@ -131,6 +131,8 @@ def load():
     L.gmr_smplx_keypoints.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int64, C.c_int64, C.c_int, vp, vp, vp]
     L.gmr_smplx_keypoints_cols.restype = C.c_int
     L.gmr_smplx_keypoints_cols.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int64, C.c_int64, C.c_int, vp, C.c_int, vp, vp, vp]
+    L.gmr_smplx_keypoints_in.restype = C.c_int
+    L.gmr_smplx_keypoints_in.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int64, C.c_int64, C.c_int, vp, C.c_int, vp, vp, vp]
     L.gmr_bvh_fk_rows.restype = C.c_int
     L.gmr_bvh_fk_rows.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int64, C.c_int64, C.c_double, vp, C.c_int, vp, vp, vp]
     L.gmr_bvh_parse_motion_device.restype = C.c_int

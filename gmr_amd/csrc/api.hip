@@ -1577,7 +1577,15 @@ static int adapter_chunk(int64_t n_frames, int groups) {
 int gmr_smplx_keypoints_cols(const int32_t *parents, int n_joints, int joints_stride, const double *global_orient, const double *full_pose,
                              const double *joints, int64_t n_frames, int64_t n_frames_out, int resample, const int32_t *out_cols, int n_out,
                              double *pos_out, double *quat_out, void *stream) {
+  return gmr_smplx_keypoints_in(parents, n_joints, joints_stride, global_orient, full_pose, joints, GMR_DTYPE_F64, n_frames, n_frames_out, resample,
+                                out_cols, n_out, pos_out, quat_out, stream);
+}
+
+int gmr_smplx_keypoints_in(const int32_t *parents, int n_joints, int joints_stride, const void *global_orient, const void *full_pose,
+                           const void *joints, int in_dtype, int64_t n_frames, int64_t n_frames_out, int resample, const int32_t *out_cols, int n_out,
+                           double *pos_out, double *quat_out, void *stream) {
   if (!parents || !global_orient || !full_pose || !joints || !pos_out || !quat_out || n_frames < 0 || n_frames_out < 0) return GMR_EINVAL;
+  if (in_dtype != GMR_DTYPE_F32 && in_dtype != GMR_DTYPE_F64) return GMR_EINVAL;
   if (n_joints < 1 || n_joints > gmr::kSmplMaxJoints || joints_stride < n_joints) return GMR_EUNSUPPORTED;
   if (!resample && n_frames_out != n_frames) return GMR_EINVAL;
   if (n_frames_out > 0 && n_frames == 0) return GMR_EINVAL;
@@ -1606,8 +1614,14 @@ int gmr_smplx_keypoints_cols(const int32_t *parents, int n_joints, int joints_st
   const int chunk = adapter_chunk(n_frames_out, gmr::chain_geom(n_joints).groups);
   const int64_t nblk = (n_frames_out + chunk - 1) / chunk;
   if (nblk > 0x7fffffff) return GMR_EINVAL;
-  hipLaunchKernelGGL(gmr::smplx_keypoints_kernel, dim3((unsigned)nblk), dim3(64), 0, static_cast<hipStream_t>(stream), sk, global_orient,
-                     full_pose, joints, n_frames, n_frames_out, chunk, pos_out, quat_out);
+  if (in_dtype == GMR_DTYPE_F32)
+    hipLaunchKernelGGL(gmr::smplx_keypoints_kernel<float>, dim3((unsigned)nblk), dim3(64), 0, static_cast<hipStream_t>(stream), sk,
+                       static_cast<const float *>(global_orient), static_cast<const float *>(full_pose), static_cast<const float *>(joints), n_frames,
+                       n_frames_out, chunk, pos_out, quat_out);
+  else
+    hipLaunchKernelGGL(gmr::smplx_keypoints_kernel<double>, dim3((unsigned)nblk), dim3(64), 0, static_cast<hipStream_t>(stream), sk,
+                       static_cast<const double *>(global_orient), static_cast<const double *>(full_pose), static_cast<const double *>(joints), n_frames,
+                       n_frames_out, chunk, pos_out, quat_out);
   return hipGetLastError() == hipSuccess ? GMR_OK : GMR_EDEVICE;
 }
 

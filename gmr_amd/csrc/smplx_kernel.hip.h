@@ -68,8 +68,11 @@ __device__ __forceinline__ void slerp_xyzw(const double q1[4], const double q2[4
 // global_orient [T][3], full_pose [T][J][3] (axis-angle), joints [T][joints_stride][3]  ->
 // pos_out [T_out][n_out][3], quat_out [T_out][n_out][4] wxyz.  resample = 0 copies frames 1:1 (T_out == T).
 // A wavefront handles output frames [blockIdx.x * chunk, ... + chunk), 64 / jp of them per iteration.
-__global__ void __launch_bounds__(64) smplx_keypoints_kernel(SmplSkeleton sk, const double *__restrict__ global_orient,
-                                                            const double *__restrict__ full_pose, const double *__restrict__ joints,
+// TIn: the input arrays' element type -- double, or float as a body model emits it (promoted to double on load, which is what the
+// reference's scipy / numpy calls do with float32 input: exact, and half the bytes).
+template <typename TIn>
+__global__ void __launch_bounds__(64) smplx_keypoints_kernel(SmplSkeleton sk, const TIn *__restrict__ global_orient,
+                                                            const TIn *__restrict__ full_pose, const TIn *__restrict__ joints,
                                                             int64_t T, int64_t T_out, int chunk, double *__restrict__ pos_out,
                                                             double *__restrict__ quat_out) {
   __shared__ double xb[4][64];
@@ -108,17 +111,17 @@ __global__ void __launch_bounds__(64) smplx_keypoints_kernel(SmplSkeleton sk, co
 #pragma unroll
     for (int c = 0; c < 3; ++c) { w.r1[c] = 0.0; w.r2[c] = 0.0; w.p1[c] = 0.0; w.p2[c] = 0.0; }
     if (ok) {
-      const double *a = j == 0 ? global_orient + i1 * 3 : full_pose + (i1 * J + j) * 3;
+      const TIn *a = j == 0 ? global_orient + i1 * 3 : full_pose + (i1 * J + j) * 3;
       w.r1[0] = a[0]; w.r1[1] = a[1]; w.r1[2] = a[2];
       if (resample) {
-        const double *b = j == 0 ? global_orient + i2 * 3 : full_pose + (i2 * J + j) * 3;
+        const TIn *b = j == 0 ? global_orient + i2 * 3 : full_pose + (i2 * J + j) * 3;
         w.r2[0] = b[0]; w.r2[1] = b[1]; w.r2[2] = b[2];
       }
       if (ocol >= 0) {
-        const double *pa = joints + (i1 * sk.joints_stride + j) * 3;
+        const TIn *pa = joints + (i1 * sk.joints_stride + j) * 3;
         w.p1[0] = pa[0]; w.p1[1] = pa[1]; w.p1[2] = pa[2];
         if (resample) {
-          const double *pb = joints + (i2 * sk.joints_stride + j) * 3;
+          const TIn *pb = joints + (i2 * sk.joints_stride + j) * 3;
           w.p2[0] = pb[0]; w.p2[1] = pb[1]; w.p2[2] = pb[2];
         }
       }

@@ -180,30 +180,112 @@ class _Pieces:
 
 
 _STREAM_TEMPLATES: Dict = {}
+_SMALL_MIN = 256  # arrays below this many bytes are part of a layout's key, like the scalars
+
+
+class _Template:
+    """The pickle of one motion layout with its numbers taken out: ``pieces`` are the stream's buffers in order -- bytes (opcodes,
+    frame headers, strings, ...), or the KEY of a large array whose memory goes there as it is; ``patches`` say where, inside the
+    bytes pieces, the raw data of the layout's small arrays lie (piece, offset, size, key).  Built from the first clip of a layout,
+    compared once against the full pickler run of the second clip (``verified``), used from the third on."""
+    __slots__ = ("pieces", "patches", "verified")
+
+    def __init__(self, pieces, patches):
+        self.pieces, self.patches, self.verified = pieces, patches, False
+
+    def fill(self, motion: Dict) -> list:
+        out = list(self.pieces)
+        touched = {}
+        for pi, off, n, k in self.patches:
+            b = touched.get(pi)
+            if b is None:
+                b = touched[pi] = bytearray(out[pi])
+                out[pi] = b
+            b[off:off + n] = memoryview(motion[k]).cast("B")
+        return [memoryview(motion[t]).cast("B") if isinstance(t, str) else t for t in out]
+
+
+def _is_plain(v) -> bool:
+    return type(v) is np.ndarray and v.flags.c_contiguous and v.dtype.kind in "fiub"
+
+
+def _full_stream(motion: Dict):
+    out = _Pieces()
+    _MotionPickler(out, pickle.DEFAULT_PROTOCOL).dump(motion)
+    return out.pieces
+
+
+def _build_template(motion: Dict, big, small) -> Optional[_Template]:
+    """Pickle a SHADOW of the clip -- same layout, the small arrays filled with random bytes -- and find those bytes in the stream: a
+    clip's own numbers can be degenerate (a block of zeros also matches the zero bytes of the length field in front of it)."""
+    rng = np.random.default_rng(0x5EED)
+    shadow = dict(motion)
+    marks = []
+    for k, v in small:
+        m = np.frombuffer(rng.bytes(v.nbytes), dtype=v.dtype).reshape(v.shape).copy()
+        shadow[k] = m
+        marks.append((k, m))
+    pieces = _full_stream(shadow)
+    small = marks
+    order = {id(v): k for k, v in big}
+    tp = []
+    for p in pieces:
+        if isinstance(p, memoryview) and id(p.obj) in order:
+            tp.append(order[id(p.obj)])
+        else:
+            tp.append(bytes(p))
+    if sum(isinstance(t, str) for t in tp) != len(big):
+        return None
+    patches, pi, pos = [], 0, 0
+    for k, v in small:  # in dict order = stream order: search on from where the previous one ended
+        raw = memoryview(v).cast("B").tobytes()
+        while pi < len(tp):
+            at = tp[pi].find(raw, pos) if isinstance(tp[pi], bytes) else -1
+            if at >= 0:
+                patches.append((pi, at, len(raw), k))
+                pos = at + len(raw)
+                break
+            pi, pos = pi + 1, 0
+        else:
+            return None
+    return _Template(tp, patches)
 
 
 def motion_stream(motion: Dict) -> list:
     """The pickle of a motion dict as a list of buffers (headers as bytes, array payloads as views of the arrays' own memory).
-    Clips of one batch differ in their numbers only, so the header pieces are kept per layout -- keys, array shapes and dtypes,
-    and the pickle of everything that is not a large array -- and a clip of a known layout costs a dict lookup, not a pickler run."""
-    big = [(k, v) for k, v in motion.items() if type(v) is np.ndarray and v.flags.c_contiguous and v.dtype.kind in "fiub" and v.nbytes >= 1 << 16]
-    big_keys = {k for k, _ in big}
-    key = (tuple(motion.keys()), tuple((k, v.shape, v.dtype.str) for k, v in big),
-           pickle.dumps([v for k, v in motion.items() if k not in big_keys], pickle.DEFAULT_PROTOCOL))
+    Clips of one batch differ in their numbers only, so the stream is kept per LAYOUT -- keys, array shapes and dtypes, and the pickle
+    of everything that is not an array -- with the numbers taken out (``_Template``): a clip of a known layout costs a dict lookup and
+    a copy of its small arrays (those below the pickler's 64 KB frame size, which travel inside frames), not a run of the pure-Python
+    pickler (~0.5 ms under the GIL: every clip shorter than 2 731 frames has such arrays).  A layout's template is checked against the
+    full pickler on the second clip that uses it before it is trusted."""
+    big = [(k, v) for k, v in motion.items() if _is_plain(v) and v.nbytes >= 1 << 16]
+    small = [(k, v) for k, v in motion.items() if _is_plain(v) and _SMALL_MIN <= v.nbytes < 1 << 16]
+    if sum(v.nbytes for _, v in big) + sum(v.nbytes for _, v in small) < 1 << 15 or any(_is_plain(v) and v.nbytes < _SMALL_MIN for v in motion.values()):
+        return [pickle.dumps(motion, pickle.DEFAULT_PROTOCOL)]  # a handful of frames: the stock pickler's copy costs nothing
+    arrays = {k for k, _ in big} | {k for k, _ in small}
+    try:
+        rest = pickle.dumps([v for k, v in motion.items() if k not in arrays], pickle.DEFAULT_PROTOCOL)
+    except Exception:
+        return _full_stream(motion)
+    key = (tuple(motion.keys()), tuple((k, v.shape, v.dtype.str) for k, v in big), tuple((k, v.shape, v.dtype.str) for k, v in small), rest)
     tmpl = _STREAM_TEMPLATES.get(key)
+    if tmpl is False:  # a layout the template cannot express
+        return _full_stream(motion)
+    if tmpl is not None and tmpl.verified:
+        return tmpl.fill(motion)
+    pieces = _full_stream(motion)
     if tmpl is None:
-        out = _Pieces()
-        _MotionPickler(out, pickle.DEFAULT_PROTOCOL).dump(motion)
-        views = [id(p.obj) if isinstance(p, memoryview) else None for p in out.pieces]
-        order = {id(v): k for k, v in big}
-        # payload pieces are views whose exporter is one of the large arrays: remember which key goes where
-        tmpl = [order[i] if i in order else p for p, i in zip(out.pieces, views)]
-        if sum(isinstance(t, str) for t in tmpl) == len(big) and all(not isinstance(t, memoryview) for t in tmpl):
-            if len(_STREAM_TEMPLATES) >= 256:
-                _STREAM_TEMPLATES.clear()
-            _STREAM_TEMPLATES[key] = tmpl
-        return out.pieces
-    return [memoryview(motion[t]).cast("B") if isinstance(t, str) else t for t in tmpl]
+        if len(_STREAM_TEMPLATES) >= 256:
+            _STREAM_TEMPLATES.clear()
+        _STREAM_TEMPLATES[key] = _build_template(motion, big, small) or False
+    else:  # second clip of the layout: the template must reproduce the pickler's stream exactly
+        a = b"".join(bytes(memoryview(x).cast("B")) for x in tmpl.fill(motion))
+        b = b"".join(bytes(memoryview(x).cast("B")) for x in pieces)
+        if a == b:
+            tmpl.verified = True
+        else:
+            _STREAM_TEMPLATES[key] = False
+    return pieces
 
 
 def _write_all(path: str, pieces: list) -> None:

@@ -461,3 +461,50 @@ def write_keypoint_files(folder: str, pos: np.ndarray, quat: np.ndarray, names: 
         _write_rows(f, header, rows.reshape(T, -1))
         files.append(f)
     return files
+
+
+def smplx_joint_arrays_from_keypoints(pos, quat, names: List[str]):
+    """Body-model-shaped arrays whose adapter output (30 fps, no resampling) is the given key-points: torch ``pos [N, B, 3]``,
+    ``quat [N, B, 4]`` (wxyz) with SMPL-X joint names -> (global_orient [N, 3], full_pose [N, 165], joints [N, 55, 3]) in float64 on the
+    same device.  Joints a config does not name keep the identity orientation and the origin; a joint's axis-angle is the rotation that
+    takes its parent's global orientation to its own (what smpl.py:179-196 chains back together)."""
+    import torch
+    from .smplx_adapter import SMPLX_JOINT_NAMES, SMPLX_PARENTS
+    N, J, dev = int(pos.shape[0]), len(SMPLX_PARENTS), pos.device
+    G = torch.zeros((N, J, 4), dtype=torch.float64, device=dev)
+    G[..., 0] = 1.0
+    P = torch.zeros((N, J, 3), dtype=torch.float64, device=dev)
+    for c, n in enumerate(names):
+        if n in SMPLX_JOINT_NAMES:
+            j = SMPLX_JOINT_NAMES.index(n)
+            q = quat[:, c].to(torch.float64)
+            G[:, j] = q / q.norm(dim=-1, keepdim=True)
+            P[:, j] = pos[:, c].to(torch.float64)
+    par = torch.as_tensor(SMPLX_PARENTS, device=dev)
+    Gp = G[:, par.clamp_min(0)]
+    Gp[:, 0] = torch.tensor([1.0, 0.0, 0.0, 0.0], dtype=torch.float64, device=dev)
+    L = _t_qmul(Gp * torch.tensor([1.0, -1.0, -1.0, -1.0], dtype=torch.float64, device=dev), G)
+    L = torch.where(L[..., :1] < 0, -L, L)
+    v = L[..., 1:]
+    s = v.norm(dim=-1, keepdim=True)
+    ang = 2.0 * torch.atan2(s, L[..., :1])
+    rv = torch.where(s > 1e-12, v / s.clamp_min(1e-300) * ang, 2.0 * v)
+    return rv[:, 0].contiguous(), rv.reshape(N, 3 * J).contiguous(), P
+
+
+def write_smplx_joint_files(folder: str, pos, quat, names: List[str], seq_offsets, fps: float = 30.0, heights: Optional[Sequence[float]] = None,
+                            prefix: str = "clip", dtype=np.float32) -> List[str]:
+    """``smplx_joint_arrays_from_keypoints`` per clip as joint-array files (``gmr_amd.smplx_adapter.save_joint_file``; float32 like a body
+    model's output unless ``dtype`` says otherwise).  ``heights``: written as betas[0] = (h - 1.66) / 0.1, what the loader inverts."""
+    import os
+    from .smplx_adapter import save_joint_file
+    go, fp, jt = (a.cpu().numpy() for a in smplx_joint_arrays_from_keypoints(pos, quat, names))
+    files = []
+    for k, (a, b) in enumerate(zip(seq_offsets[:-1], seq_offsets[1:])):
+        betas = np.zeros(16)
+        if heights is not None:
+            betas[0] = (float(heights[k]) - 1.66) / 0.1
+        f = os.path.join(folder, f"{prefix}_{k:05d}.npz")
+        save_joint_file(f, jt[a:b].astype(dtype), go[a:b].astype(dtype), fp[a:b].astype(dtype), fps, betas)
+        files.append(f)
+    return files

@@ -35,7 +35,7 @@
  *   gmr_dof_to_rot     KinematicsModel.dof_to_rot (kinematics_model.py:172-182; Joint.dof_to_rot :21-36)
  *   gmr_rot_to_dof     KinematicsModel.rot_to_dof (kinematics_model.py:184-197; Joint.rot_to_dof :38-53), clamped to the joint limits
  *   gmr_local_rot_to_global  KinematicsModel.convert_local_rot_to_global (kinematics_model.py:199-211)
- *   gmr_smplx_keypoints, gmr_smplx_keypoints_cols  the numeric part of get_smplx_data_offline_fast (general_motion_retargeting/utils/smpl.py:109-198)
+ *   gmr_smplx_keypoints, gmr_smplx_keypoints_cols, gmr_smplx_keypoints_in  the numeric part of get_smplx_data_offline_fast (general_motion_retargeting/utils/smpl.py:109-198)
  *                      after the SMPL-X body model: slerp/lerp to the target frame rate, orientation chaining
  *   gmr_bvh_parse_header the HIERARCHY section of read_bvh (general_motion_retargeting/utils/lafan_vendor/extract.py:60-139)
  *   gmr_bvh_parse_motion, gmr_bvh_parse_motion_device  the MOTION block of read_bvh (general_motion_retargeting/utils/lafan_vendor/extract.py:140-166): the
@@ -243,6 +243,13 @@ int gmr_smplx_keypoints(const int32_t *parents, int n_joints, int joints_stride,
 int gmr_smplx_keypoints_cols(const int32_t *parents, int n_joints, int joints_stride, const double *global_orient, const double *full_pose,
                              const double *joints, int64_t n_frames, int64_t n_frames_out, int resample, const int32_t *out_cols, int n_out,
                              double *pos_out, double *quat_out, void *stream);
+
+/* The same for input arrays of either element type: in_dtype GMR_DTYPE_F32 (what a body model emits: the arrays go in as they are,
+ * each element promoted to float64 on load -- exactly what the reference's scipy / numpy calls do with float32 input -- at half the
+ * bytes) or GMR_DTYPE_F64.  global_orient, full_pose, joints: device arrays of that type, shapes as above.                        */
+int gmr_smplx_keypoints_in(const int32_t *parents, int n_joints, int joints_stride, const void *global_orient, const void *full_pose,
+                           const void *joints, int in_dtype, int64_t n_frames, int64_t n_frames_out, int resample, const int32_t *out_cols,
+                           int n_out, double *pos_out, double *quat_out, void *stream);
 
 /* Host-side parse of a BVH file's HIERARCHY section and MOTION header (stateless, no device involved; grammar and the
  * reference semantics it keeps are documented in gmr_amd/csrc/bvh_text.h).  Replaces the hierarchy loop of read_bvh

@@ -447,3 +447,73 @@ def test_bvh_folder_skip_errors(golden_dir, tmp_path):
     assert [bb.files for bb in got] == [[good], [g2]] and sum(len(bb.skipped) for bb in got) == 4
     only_bad = list(iter_lafan1_batches([junk, ragged], batch_files=1, skip_errors=True))
     assert [len(bb) for bb in only_bad] == [0, 0] and len(only_bad[0].skipped) == 1
+
+
+def test_smplx_joint_files_equal_per_clip_adapter_calls(tmp_path):
+    """smplx_adapter.load_joint_files / iter_joint_batches (the file side of row f-2): every clip of the batch is, bit for bit, what
+    get_smplx_data_offline_fast returns for that clip's arrays -- 120 -> 30 fps and 1:1 clips in one batch, float32 files (a body model's
+    dtype) and float64 ones, all 55 columns and a config's 14; heights follow load_smplx_file's betas rule (utils/smpl.py:37-40), fps
+    the aligned rate (:172); a broken file is reported, not fatal, with skip_errors."""
+    from gmr_amd import GeneralMotionRetargeting as GMR, synth
+    from gmr_amd import smplx_adapter as sa
+    dev = torch.device("cuda", 0)
+    g = GMR(src_human="smplx", tgt_robot="unitree_g1")
+    files, arrays = [], []
+    for k, (T, fps, dt) in enumerate([(481, 120.0, np.float32), (90, 30.0, np.float64), (7, 120.0, np.float32), (250, 60.0, np.float64)]):
+        go, fp, jt = (a.cpu().numpy().astype(dt) for a in synth.smplx_arrays_torch(T, dev, seed=k))
+        betas = np.zeros(16) if k % 2 else np.zeros((1, 16))
+        betas.reshape(-1)[0] = 0.3 * k - 0.4
+        f = str(tmp_path / f"c{k}.npz")
+        sa.save_joint_file(f, jt, go, fp.reshape(T, -1), fps, betas)
+        files.append(f)
+        arrays.append((go, fp, jt[:, :55], fps, 1.66 + 0.1 * (0.3 * k - 0.4)))
+    z = np.load(files[0])
+    assert z["joints"].shape == (481, 55, 3) and z["joints"].dtype == np.float32 and z["full_pose"].shape == (481, 165)
+    for cols in (None, g.ik_columns):
+        b = sa.load_joint_files(files, columns=cols)
+        assert len(b) == 4 and b.files == files and b.body_names == (sa.SMPLX_JOINT_NAMES if cols is None else cols)
+        assert b.seq_offsets.tolist() == [0, 120, 210, 211, 336]
+        for k, (go, fp, jt, fps, h) in enumerate(arrays):
+            p, q, names, afps = sa.get_smplx_data_offline_fast(go.astype(np.float64), fp.astype(np.float64), jt.astype(np.float64), src_fps=fps, columns=cols)
+            a, e = b.seq_offsets[k], b.seq_offsets[k + 1]
+            assert torch.equal(b.pos[a:e], p) and torch.equal(b.quat[a:e], q) and b.fps[k] == afps
+            assert abs(b.human_heights[k] - h) < 1e-12
+    bad = str(tmp_path / "broken.npz")
+    np.savez(bad, joints=np.zeros((4, 10, 3)), global_orient=np.zeros((4, 3)), full_pose=np.zeros((4, 165)), mocap_frame_rate=30.0, betas=np.zeros(16))
+    with pytest.raises(ValueError):
+        sa.load_joint_files(files[:1] + [bad])
+    got = list(sa.iter_joint_batches([files[0], bad, str(tmp_path / "missing.npz"), files[1]], batch_files=2, skip_errors=True))
+    assert [bb.files for bb in got] == [[files[0]], [files[1]]] and [len(bb.skipped) for bb in got] == [1, 1]
+    assert torch.equal(got[1].pos, sa.load_joint_files([files[1]]).pos)
+
+
+def test_smplx_joint_files_to_pickles_pipeline(tmp_path):
+    """The loop body of scripts/smplx_to_robot_dataset.py:63-146 behind the body model: joint-array files -> adapter -> batched IK with one
+    actual_human_height per file -> FK / height adjust / xy offset -> pickles written by the pool.  The files hold robot-consistent
+    key-points (gmr_amd.synth.write_smplx_joint_files), so the result must be what solving those key-points in memory gives."""
+    from gmr_amd import GeneralMotionRetargeting as GMR, dataset, synth
+    from gmr_amd import smplx_adapter as sa
+    dev = torch.device("cuda", 0)
+    g = GMR(src_human="smplx", tgt_robot="unitree_g1")
+    cm = g._cm
+    lens = np.array([120, 77, 200, 64, 150])
+    heights = [1.6, 1.7, 1.75, 1.8, 1.66]
+    pos, quat, names, offs = synth.synth_clips_torch(cm, lens, seed=3, device=dev, hard=np.arange(5) % 2 == 1, yaw0=1.0, dtype=torch.float64)
+    files = synth.write_smplx_joint_files(str(tmp_path), pos, quat, names, offs, fps=30.0, heights=heights, dtype=np.float64)
+    outs = [str(tmp_path / "out" / f"m{i}.pkl") for i in range(5)]
+    k, kp_err = 0, 0.0
+    with dataset.MotionWriter(workers=2) as w:
+        for batch in sa.iter_joint_batches(files, batch_files=2, columns=g.ik_columns):
+            a, e = offs[k], offs[k + len(batch)]
+            cols = [names.index(c) for c in batch.body_names]
+            kp_err = max(kp_err, float((batch.pos - pos[a:e][:, cols]).abs().max()), float(torch.minimum((batch.quat - quat[a:e][:, cols]).abs().amax(-1), (batch.quat + quat[a:e][:, cols]).abs().amax(-1)).max()))
+            assert np.allclose(batch.human_heights, heights[k:k + len(batch)], atol=1e-12) and batch.fps == [30.0] * len(batch)
+            motions = dataset.retarget_clips(g, batch.pos, batch.quat, batch.body_names, batch.seq_offsets, fps=batch.fps, human_heights=batch.human_heights)
+            w.submit(motions, outs[k:k + len(batch)])
+            k += len(batch)
+    assert w.written == 5 and kp_err < 1e-9
+    ref = dataset.retarget_clips(GMR(src_human="smplx", tgt_robot="unitree_g1"), pos, quat, names, offs, fps=30.0, human_heights=heights)
+    for o, r in zip(outs, ref):
+        d, fps, rp, rr, dp, lb, bn = dataset.load_robot_motion(o)
+        dataset.validate_motion(d, nq=36)
+        assert fps == 30.0 and np.abs(dp - r["dof_pos"]).max() < 1e-6 and np.abs(rp - r["root_pos"]).max() < 1e-6

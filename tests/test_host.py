@@ -460,3 +460,30 @@ def test_bvh_text_entry_points_survive_hostile_input():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_bvh_text.py"), "3", "5"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 violations" in r.stdout
+
+
+def test_motion_stream_templates_are_byte_identical_for_every_clip_length():
+    """dataset.motion_stream: a layout's pickle is kept as a template with the numbers taken out (large arrays as views, the small ones --
+    below the pickler's 64 KB frame size, i.e. every clip shorter than 2 731 frames has some -- patched into the framed bytes).  Whatever
+    the length and however degenerate the data (blocks of zeros also match the zero bytes of a length field: templates are built from a
+    random-filled shadow and checked on the second clip), the stream must be pickle.dumps(motion) byte for byte."""
+    import pickle
+    from gmr_amd import dataset
+    assert dataset.fast_pickle_ok()
+    rng = np.random.default_rng(3)
+    for T in (0, 1, 7, 40, 100, 300, 750, 1366, 1500, 2047, 2049, 2731, 3000):
+        ms = [{"fps": 30.0 if T % 2 else 30, "root_pos": rng.random((T, 3)), "root_rot": rng.random((T, 4)), "dof_pos": rng.random((T, 29)),
+               "local_body_pos": rng.random((T, 38, 3)).astype(np.float32), "link_body_list": [f"b{i}" for i in range(38)]} for _ in range(8)]
+        for i in (0, 1, 4):
+            ms[i]["root_pos"][:] = 0
+            ms[i]["root_rot"][:] = 0
+        ms[5]["dof_pos"][:] = 0
+        ms[6]["local_body_pos"][:] = 0
+        ms[7]["root_pos"][:] = ms[7]["root_rot"][:, :3]
+        for rep in range(2):
+            for m in ms:
+                got = b"".join(bytes(memoryview(x).cast("B")) for x in dataset.motion_stream(m))
+                assert got == pickle.dumps(m), (T, rep)
+    # a dict the template cannot express (an object array) still comes out right
+    odd = {"fps": 30, "root_pos": np.zeros((500, 3)), "names": np.array(["a", None], dtype=object)}
+    assert b"".join(bytes(memoryview(x).cast("B")) for x in dataset.motion_stream(odd)) == pickle.dumps(odd)

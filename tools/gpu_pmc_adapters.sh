@@ -17,7 +17,7 @@ while read -r C; do
 import csv, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
-    for key in ("bvh_fk_kernel", "smplx_keypoints_kernel"):
+    for key in ("bvh_fk_kernel", "smplx_keypoints_kernel<double>"):
         if key in r["Kernel_Name"]:
             acc[key][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
 for key, d in acc.items():
