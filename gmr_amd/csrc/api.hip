@@ -1590,28 +1590,41 @@ int gmr_smplx_keypoints_in(const int32_t *parents, int n_joints, int joints_stri
   if (!resample && n_frames_out != n_frames) return GMR_EINVAL;
   if (n_frames_out > 0 && n_frames == 0) return GMR_EINVAL;
   gmr::SmplSkeleton sk{};
-  sk.n_joints = n_joints; sk.joints_stride = joints_stride; sk.resample = resample ? 1 : 0;
+  sk.joints_stride = joints_stride; sk.pose_stride = n_joints; sk.resample = resample ? 1 : 0;
   if (parents[0] != -1) return GMR_EINVAL;
-  for (int j = 0; j < n_joints; ++j) {
-    if (j > 0 && (parents[j] < 0 || parents[j] >= j)) return GMR_EINVAL;
-    sk.parent[j] = (short)parents[j];
-  }
+  for (int j = 1; j < n_joints; ++j)
+    if (parents[j] < 0 || parents[j] >= j) return GMR_EINVAL;
+  short col_of[gmr::kSmplMaxJoints];      /* output column of model joint j, -1 = not emitted */
+  unsigned char live[gmr::kSmplMaxJoints]; /* emitted, or an ancestor of an emitted joint */
   if (out_cols) {  /* out_cols[c] = joint emitted as column c; ancestors are chained internally */
     if (n_out < 1 || n_out > n_joints) return GMR_EINVAL;
-    for (int j = 0; j < n_joints; ++j) { sk.out_col[j] = -1; sk.live[j] = 0; }
+    for (int j = 0; j < n_joints; ++j) { col_of[j] = -1; live[j] = 0; }
     for (int c = 0; c < n_out; ++c) {
       const int j = out_cols[c];
-      if (j < 0 || j >= n_joints || sk.out_col[j] >= 0) return GMR_EINVAL;
-      sk.out_col[j] = (short)c;
-      for (int a = j; a >= 0 && !sk.live[a]; a = parents[a]) sk.live[a] = 1;
+      if (j < 0 || j >= n_joints || col_of[j] >= 0) return GMR_EINVAL;
+      col_of[j] = (short)c;
+      for (int a = j; a >= 0 && !live[a]; a = parents[a]) live[a] = 1;
     }
     sk.n_out = n_out;
   } else {
-    for (int j = 0; j < n_joints; ++j) { sk.out_col[j] = (short)j; sk.live[j] = 1; }
+    for (int j = 0; j < n_joints; ++j) { col_of[j] = (short)j; live[j] = 1; }
     sk.n_out = n_joints;
   }
+  /* the kernel's skeleton: the live joints only, renumbered in order (a parent precedes its children, the root stays first) */
+  short cidx[gmr::kSmplMaxJoints];
+  int nl = 0;
+  for (int j = 0; j < n_joints; ++j) {
+    cidx[j] = -1;
+    if (!live[j]) continue;
+    cidx[j] = (short)nl;
+    sk.src[nl] = (short)j;
+    sk.out_col[nl] = col_of[j];
+    sk.parent[nl] = j == 0 ? (short)-1 : cidx[parents[j]];
+    ++nl;
+  }
+  sk.n_joints = nl;
   if (n_frames_out == 0) return GMR_OK;
-  const int chunk = adapter_chunk(n_frames_out, gmr::chain_geom(n_joints).groups);
+  const int chunk = adapter_chunk(n_frames_out, gmr::chain_geom(nl).groups);
   const int64_t nblk = (n_frames_out + chunk - 1) / chunk;
   if (nblk > 0x7fffffff) return GMR_EINVAL;
   if (in_dtype == GMR_DTYPE_F32)
@@ -1714,6 +1727,7 @@ int64_t gmr_bvh_parse_motion(const char *text, size_t len, int64_t max_lines, do
         while (t < end && !(*t == ' ' || *t == '\t' || *t == '\r' || *t == '\n')) ++t;
         std::string buf(tok, t);
         char *stop = nullptr;
+        if (!gmr_bvh::float_token(buf.data(), buf.size())) return -1;  // (what strtod would take but Python's float() does not: hex, nan(...))
         v = strtod(buf.c_str(), &stop);
         if (buf.empty() || stop != buf.c_str() + buf.size()) return -1;
         p = t;

@@ -42,8 +42,39 @@ struct Header {
   int n = 0;
 };
 
+// The tokens strtod and Python's float() read ALIKE: [+-] digits [. digits] [(e|E) [+-] digits] with at least one mantissa digit, or
+// inf / infinity / nan in any case.  strtod alone would also take hexadecimal floats ("0x10" = 16) and "nan(...)", which float() --
+// what the reference parses every number with (extract.py:140-156) -- rejects; float() alone also takes digit-group underscores
+// ("1_0"), which are refused here: a refused token fails the file, it never yields a different number.
+inline bool float_token(const char *s, size_t n) {
+  size_t i = 0;
+  if (i < n && (s[i] == '+' || s[i] == '-')) ++i;
+  auto word = [&](const char *w) {
+    size_t k = 0;
+    for (; w[k]; ++k)
+      if (i + k >= n || (s[i + k] | 0x20) != w[k]) return false;
+    return i + k == n;
+  };
+  if (word("inf") || word("infinity") || word("nan")) return true;
+  bool digits = false;
+  while (i < n && s[i] >= '0' && s[i] <= '9') { digits = true; ++i; }
+  if (i < n && s[i] == '.') {
+    ++i;
+    while (i < n && s[i] >= '0' && s[i] <= '9') { digits = true; ++i; }
+  }
+  if (!digits) return false;
+  if (i < n && (s[i] == 'e' || s[i] == 'E')) {
+    ++i;
+    if (i < n && (s[i] == '+' || s[i] == '-')) ++i;
+    bool ed = false;
+    while (i < n && s[i] >= '0' && s[i] <= '9') { ed = true; ++i; }
+    if (!ed) return false;
+  }
+  return i == n;
+}
+
 inline bool number(Cursor &c, double &v) {
-  if (!c.next() || c.len == 0 || c.len > 63) return false;
+  if (!c.next() || c.len == 0 || c.len > 63 || !float_token(c.tok, c.len)) return false;
   char buf[64];
   memcpy(buf, c.tok, c.len);
   buf[c.len] = 0;

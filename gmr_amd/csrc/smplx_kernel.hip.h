@@ -9,7 +9,7 @@
 // One wavefront per run of output frames, lane = joint (tree_chain.hip.h): the two source rows of a frame are read densely by
 // the joints' lanes, the slerp of all joints runs side by side, the orientations are chained by pointer jumping through the LDS
 // exchange buffer, and each output row is written once.  `out_col` emits only the columns a consumer names (the 14 joints an IK
-// config reads); joints that are neither emitted nor an ancestor of an emitted one are not even loaded.
+// config reads); joints that are neither emitted nor an ancestor of an emitted one take no lane at all (SmplSkeleton).
 #pragma once
 
 #include "tree_chain.hip.h"
@@ -18,11 +18,15 @@ namespace gmr {
 
 constexpr int kSmplMaxJoints = 64;
 
+// The skeleton the kernel works on holds only the LIVE joints -- those emitted or an ancestor of an emitted one --, renumbered densely
+// (parents before children, the root first): with the 14 columns an smplx_to_*.json config reads that is ~22 of SMPL-X's 55 joints, so
+// two frames share a wavefront (chain_geom) where the full tree takes one.  `src` leads back to the joint's place in the input rows.
 struct SmplSkeleton {
-  int n_joints, joints_stride, resample, n_out;  // joints_stride: joints per frame in the position array (>= n_joints)
-  short parent[kSmplMaxJoints];
-  short out_col[kSmplMaxJoints];   // output column of joint j, -1 = not emitted
-  unsigned char live[kSmplMaxJoints];  // 1 = emitted or an ancestor of an emitted joint
+  int n_joints, joints_stride, resample, n_out;  // n_joints: live joints; joints_stride: joints per frame in the position array
+  int pose_stride;                               // joints per frame in full_pose (the model's joint count)
+  short parent[kSmplMaxJoints];    // parent of live joint c (an index into the live joints), -1 for the root
+  short out_col[kSmplMaxJoints];   // output column of live joint c, -1 = not emitted (a mere ancestor)
+  short src[kSmplMaxJoints];       // the model's index of live joint c
 };
 
 __device__ __forceinline__ void quat_mul_xyzw(const double a[4], const double b[4], double o[4]) {
@@ -83,9 +87,10 @@ __global__ void __launch_bounds__(64) smplx_keypoints_kernel(SmplSkeleton sk, co
   const int jp = geo.jp, G = geo.groups;
   const int j = G > 1 ? (lane & (jp - 1)) : lane;
   const int grp = G > 1 ? lane / jp : 0;
-  const bool has = j < J && sk.live[j < J ? j : 0] != 0;
+  const bool has = j < J;
   const int par = has ? (int)sk.parent[j] : -1;
   const int ocol = has ? (int)sk.out_col[j] : -1;
+  const int jo = has ? (int)sk.src[j] : 0;  // where this joint's numbers are in the input rows
   int pslot[1] = {par >= 0 ? lane - j + par : -1};
   unsigned long long plan[1];
   const int rounds = chain_plan<1>(pslot, lane, xi, plan);
@@ -111,17 +116,17 @@ __global__ void __launch_bounds__(64) smplx_keypoints_kernel(SmplSkeleton sk, co
 #pragma unroll
     for (int c = 0; c < 3; ++c) { w.r1[c] = 0.0; w.r2[c] = 0.0; w.p1[c] = 0.0; w.p2[c] = 0.0; }
     if (ok) {
-      const TIn *a = j == 0 ? global_orient + i1 * 3 : full_pose + (i1 * J + j) * 3;
+      const TIn *a = jo == 0 ? global_orient + i1 * 3 : full_pose + (i1 * sk.pose_stride + jo) * 3;
       w.r1[0] = a[0]; w.r1[1] = a[1]; w.r1[2] = a[2];
       if (resample) {
-        const TIn *b = j == 0 ? global_orient + i2 * 3 : full_pose + (i2 * J + j) * 3;
+        const TIn *b = jo == 0 ? global_orient + i2 * 3 : full_pose + (i2 * sk.pose_stride + jo) * 3;
         w.r2[0] = b[0]; w.r2[1] = b[1]; w.r2[2] = b[2];
       }
       if (ocol >= 0) {
-        const TIn *pa = joints + (i1 * sk.joints_stride + j) * 3;
+        const TIn *pa = joints + (i1 * sk.joints_stride + jo) * 3;
         w.p1[0] = pa[0]; w.p1[1] = pa[1]; w.p1[2] = pa[2];
         if (resample) {
-          const TIn *pb = joints + (i2 * sk.joints_stride + j) * 3;
+          const TIn *pb = joints + (i2 * sk.joints_stride + jo) * 3;
           w.p2[0] = pb[0]; w.p2[1] = pb[1]; w.p2[2] = pb[2];
         }
       }

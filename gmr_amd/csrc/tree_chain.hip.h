@@ -101,19 +101,25 @@ __device__ __forceinline__ void sincos_short(double x, double *sn, double *cs) {
   *sn = 2.0 * s1 * c1;
   *cs = fma(-2.0 * s1, s1, 1.0);
 }
-// N half-angles at once: the short kernels when no lane of the wavefront has an argument beyond 1.6 (angles within +-183 degrees --
-// what mocap channels and rotation vectors hold), else the range-reducing ones; decided with one ballot, so any input is handled.
+// N half-angles at once: the short kernels for every argument within 1.6 (angles within +-183 degrees -- what mocap channels and
+// rotation vectors hold), the range-reducing ones for the others.  Which kernel an element gets depends on ITS value only: one ballot
+// skips the slow path when no lane needs it, but a lane's result never depends on what its neighbours hold -- a column selection or another
+// packing of frames into wavefronts must not change a single bit of a joint's output.
 template <int N>
 __device__ __forceinline__ void sincos_n(const double (&x)[N], double (&sn)[N], double (&cs)[N]) {
   bool big = false;
 #pragma unroll
-  for (int i = 0; i < N; ++i) big |= !(fabs(x[i]) <= 1.6);
-  if (__ballot(big) == 0) {
+  for (int i = 0; i < N; ++i) {
+    big |= !(fabs(x[i]) <= 1.6);
+    sincos_short(x[i], &sn[i], &cs[i]);
+  }
+  if (__ballot(big) != 0) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) sincos_short(x[i], &sn[i], &cs[i]);
-  } else {
-#pragma unroll
-    for (int i = 0; i < N; ++i) sincos_small(x[i], &sn[i], &cs[i]);
+    for (int i = 0; i < N; ++i) {
+      double s, c;
+      sincos_small(x[i], &s, &c);
+      if (!(fabs(x[i]) <= 1.6)) { sn[i] = s; cs[i] = c; }
+    }
   }
 }
 

@@ -252,6 +252,18 @@ def test_bvh_motion_parser_matches_python_float():
     for bad in (b"1 2 3\n4 5\n", b"1 2x 3\n", b"1 - 3\n", b"1 2 3 4 5 6 7 8 9\n" * 2):
         cap = 8 if bad.startswith(b"1 2 3 4") else len(out)
         assert lib.gmr_bvh_parse_motion(bad, len(bad), 10, out.ctypes.data, cap, C.byref(nl), C.byref(nc)) == -1
+    # tokens off the fast path go to strtod -- but only those float() reads the same way: strtod alone would take hexadecimal floats
+    # and nan(...) (found by tools/fuzz_adapters.py's hostile text: "0x10" came back as 16.0 where the reference raises)
+    for tok in ("0x10", "0X1p3", "nan(1)", "1e", "1e+", "+", ".", "1..2", "1e5e5", "infinit", "1_0"):
+        bad = f"1.5 {tok} 2\n".encode()
+        assert lib.gmr_bvh_parse_motion(bad, len(bad), 10, out.ctypes.data, len(out), C.byref(nl), C.byref(nc)) == -1, tok
+        if tok != "1_0":   # (float() takes digit-group underscores; refused here: an error, never another number)
+            with pytest.raises(ValueError):
+                float(tok)
+    for tok in ("inf", "-Infinity", "+INF", "NaN", "-nan", "1e999", "-1e-999", "0." + "0" * 80 + "1", "+.5e+2", "5.E3"):
+        good = f"{tok} 1\n".encode()
+        assert lib.gmr_bvh_parse_motion(good, len(good), 10, out.ctypes.data, len(out), C.byref(nl), C.byref(nc)) == 2, tok
+        assert np.array_equal(out[:1], [float(tok)], equal_nan=True) and np.signbit(out[0]) == np.signbit(float(tok))
 
 
 def test_bvh_header_tokenizer_grammar(tmp_path):
