@@ -24,7 +24,7 @@ def run(n_files=512, T=750, threads=16, device=0, reps=3, batch_files=256, chunk
     from gmr_amd import smplx_adapter as sa
     dev = torch.device("cuda", device)
     tmpd = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
-    res = {"files": n_files, "frames": n_files * T, "threads": threads, "batch_files": batch_files}
+    res = {"files": n_files, "frames": n_files * T, "threads": threads, "batch_files": batch_files, "chunk": chunk}
     try:
         g = GMR(src_human="smplx", tgt_robot="unitree_g1")
         cm = g._cm
@@ -50,7 +50,7 @@ def run(n_files=512, T=750, threads=16, device=0, reps=3, batch_files=256, chunk
         def to_qpos():
             out = []
             for b in sa.iter_joint_batches(files, batch_files=batch_files, threads=threads, columns=cols):
-                out.append(g.retarget_batch(b.pos, b.quat, b.body_names, seq_offsets=b.seq_offsets, human_heights=b.human_heights))
+                out.append(g.retarget_batch(b.pos, b.quat, b.body_names, seq_offsets=b.seq_offsets, human_heights=b.human_heights, chunk=chunk))
             return torch.cat(out)
         t_q, q_files = timed(to_qpos)
 
@@ -58,7 +58,7 @@ def run(n_files=512, T=750, threads=16, device=0, reps=3, batch_files=256, chunk
             k = 0
             with dataset.MotionWriter(workers=max(2, min(16, threads)), override=True) as w:
                 for b in sa.iter_joint_batches(files, batch_files=batch_files, threads=threads, columns=cols):
-                    motions = dataset.retarget_clips(g, b.pos, b.quat, b.body_names, b.seq_offsets, fps=b.fps, human_heights=b.human_heights)
+                    motions = dataset.retarget_clips(g, b.pos, b.quat, b.body_names, b.seq_offsets, fps=b.fps, human_heights=b.human_heights, chunk=chunk)
                     w.submit(motions, [os.path.join(d_out, os.path.basename(f)[:-4] + ".pkl") for f in b.files])
                     k += len(b)
             return w.written
@@ -77,4 +77,5 @@ def run(n_files=512, T=750, threads=16, device=0, reps=3, batch_files=256, chunk
 if __name__ == "__main__":
     a = [int(x) for x in sys.argv[1:5]]
     a = a + [512, 750, 16, 256][len(a):]
-    print(json.dumps(run(a[0], a[1], a[2], batch_files=a[3])))
+    chunk = sys.argv[5] if len(sys.argv) > 5 else 0
+    print(json.dumps(run(a[0], a[1], a[2], batch_files=a[3], chunk=chunk if chunk == "auto" else int(chunk))))
