@@ -707,6 +707,23 @@ def main():
                                   "persistent": {"median_latency_us": float(np.median(plat)), "p99_latency_us": float(np.quantile(plat, 0.99)),
                                                  "frames_per_s": float(1e6 / plat.mean()),
                                                  "includes": "host staging + mailbox post + resident wavefront's solve + acknowledgement (no launch, no stream sync)"}}
+        # ... and through the class the reference's scripts call: `GeneralMotionRetargeting.retarget(frame_dict)` (motion_retarget.py:139-185),
+        # a dict of 55 (pos, quat) pairs in, a fresh float64[nq] out -- what a live loop or an unmodified dataset script pays per frame
+        try:
+            from gmr_amd import GeneralMotionRetargeting as _GMR
+            gcls = _GMR(src_human=SRC, tgt_robot=ROBOT)
+            frames_d = [{n: (hp[i, c].astype(np.float64), hq[i, c].astype(np.float64)) for c, n in enumerate(names)} for i in range(256)]
+            clat = []
+            for fd in frames_d:
+                t1 = time.perf_counter()
+                gcls.retarget(fd)
+                clat.append(time.perf_counter() - t1)
+            clat = np.array(clat[16:]) * 1e6
+            result["live_session"]["class_api"] = {"median_latency_us": float(np.median(clat)), "p99_latency_us": float(np.quantile(clat, 0.99)), "frames_per_s": float(1e6 / clat.mean()),
+                                                   "includes": "GeneralMotionRetargeting.retarget(dict): dict -> arrays, session step, qpos copy; the reference's own figure is 35-70 frames/s"}
+            del gcls, frames_d
+        except Exception as ex:
+            result["live_session"]["class_api"] = {"error": repr(ex)}
         # the same path fed from / returned to HOST arrays (what retarget_batch does for numpy callers): PCIe inclusive,
         # pinned double-buffered staging, copies overlapped with the kernel (Engine.ik_solve_host); never part of `value`
         nh = S * T
