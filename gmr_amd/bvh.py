@@ -533,6 +533,13 @@ def iter_lafan1_batches(bvh_files, batch_files: int = 32, device: int = 0, threa
                                np.zeros(1, dtype=np.int64), [], [], [], list(ft.skipped))
                 continue
             a0, rows, offs, files_g, frametimes, skipped = _rows_on_device(ft, dev, None, skip_errors)
-            pos, quat, names = _device_fk(a0, rows, dev, columns)
+            try:
+                pos, quat, names = _device_fk(a0, rows, dev, columns)
+            except KeyError as ex:  # the skeleton lacks a bone the caller asked for (the reference fails at its first retarget(): KeyError)
+                if not skip_errors:
+                    raise
+                yield BvhBatch(torch.empty((0, 0, 3), dtype=torch.float64, device=dev), torch.empty((0, 0, 4), dtype=torch.float64, device=dev), [],
+                               np.zeros(1, dtype=np.int64), [], [], [], list(skipped) + [(f, str(ex.args[0])) for f in files_g])
+                continue
             heights = _clip_heights(a0, rows, offs, dev, full=(pos, names) if columns is None else None)
             yield BvhBatch(pos, quat, names, offs, heights, frametimes, files_g, skipped)

@@ -517,3 +517,56 @@ def test_smplx_joint_files_to_pickles_pipeline(tmp_path):
         d, fps, rp, rr, dp, lb, bn = dataset.load_robot_motion(o)
         dataset.validate_motion(d, nq=36)
         assert fps == 30.0 and np.abs(dp - r["dof_pos"]).max() < 1e-6 and np.abs(rp - r["root_pos"]).max() < 1e-6
+
+
+def test_dataset_script_twins_end_to_end(golden_dir, tmp_path, capsys):
+    """python -m gmr_amd.scripts.{bvh,smplx}_to_robot_dataset: the reference's flags, folder walk, exclusions and output files
+    (scripts/bvh_to_robot_dataset.py:59-151, scripts/smplx_to_robot_dataset.py:171-245) with the loops run on the GPU; a second run skips what
+    exists, --override rewrites it, a broken file is reported and skipped, another skeleton in the same folder is converted in its own batch."""
+    import os
+    import shutil
+    from gmr_amd import dataset, synth, GeneralMotionRetargeting as GMR
+    from gmr_amd.scripts import bvh_to_robot_dataset, smplx_to_robot_dataset
+    src, tgt = str(tmp_path / "bvh_in"), str(tmp_path / "bvh_out")
+    os.makedirs(os.path.join(src, "sub"))
+    for n in ("a1.bvh", "a2.bvh", os.path.join("sub", "b1.bvh")):
+        shutil.copy(os.path.join(golden_dir, "bvh_lafan_like.bvh"), os.path.join(src, n))
+    # the same bones with another limb length: a second skeleton in the folder; and a skeleton without the bones bvh_to_g1.json names
+    txt = open(os.path.join(golden_dir, "bvh_lafan_like.bvh")).read().split("\n")
+    k = [i for i, ln in enumerate(txt) if "OFFSET" in ln][3]
+    txt[k] = txt[k].replace("OFFSET", "OFFSET 0.5 0.25 0.125 #").split("#")[0]
+    open(os.path.join(src, "other_skeleton.bvh"), "w").write("\n".join(txt))
+    shutil.copy(os.path.join(golden_dir, "bvh_canonical_40f.bvh"), os.path.join(src, "zz_foreign_bones.bvh"))
+    open(os.path.join(src, "broken.bvh"), "w").write("HIERARCHY\nROOT x {")
+    open(os.path.join(src, "readme.txt"), "w").write("not motion")
+    assert bvh_to_robot_dataset.main(["--src_folder", src, "--tgt_folder", tgt, "--robot", "unitree_g1", "--batch_files", "8"]) == 0
+    out = capsys.readouterr().out
+    assert "Error loading" in out and "broken.bvh" in out and "zz_foreign_bones.bvh" in out and "no such bone" in out and "Done." in out
+    made = sorted(os.path.relpath(os.path.join(d, f), tgt) for d, _, fs in os.walk(tgt) for f in fs)
+    assert made == ["a1.pkl", "a2.pkl", "other_skeleton.pkl", os.path.join("sub", "b1.pkl")]
+    for m in made:
+        d, fps, rp, rr, dp, lb, names = dataset.load_robot_motion(os.path.join(tgt, m))
+        dataset.validate_motion(d, nq=36)
+        assert fps == 30
+    t0 = os.path.getmtime(os.path.join(tgt, "a1.pkl"))
+    assert bvh_to_robot_dataset.main(["--src_folder", src, "--tgt_folder", tgt]) == 0
+    assert "(4 skipped: target exists)" in capsys.readouterr().out and os.path.getmtime(os.path.join(tgt, "a1.pkl")) == t0
+    # SMPL-X joint files
+    dev = torch.device("cuda", 0)
+    g = GMR(src_human="smplx", tgt_robot="unitree_g1")
+    lens = np.array([60, 45, 30, 20])
+    pos, quat, names, offs = synth.synth_clips_torch(g._cm, lens, seed=8, device=dev, yaw0=1.0, dtype=torch.float64)
+    s2, t2 = str(tmp_path / "sm_in"), str(tmp_path / "sm_out")
+    os.makedirs(s2)
+    files = synth.write_smplx_joint_files(s2, pos, quat, names, offs, fps=30.0, heights=[1.7, 1.6, 1.8, 1.75])
+    os.rename(files[2], os.path.join(s2, "clip_crawl_7.npz"))          # excluded by name (:218-227)
+    os.rename(files[3], os.path.join(s2, "subject_stagei.npz"))        # excluded by suffix (:208-209)
+    assert smplx_to_robot_dataset.main(["--src_folder", s2, "--tgt_folder", t2, "--robot", "unitree_g1", "--num_cpus", "2", "--hard_motions"]) == 0
+    out = capsys.readouterr().out
+    assert "full args_list: 3" in out and "new args_list: 2" in out
+    assert sorted(os.listdir(t2)) == ["clip_00000.pkl", "clip_00001.pkl"]
+    ref = dataset.retarget_clips(GMR(src_human="smplx", tgt_robot="unitree_g1"), pos[: offs[2]], quat[: offs[2]], names, offs[:3], fps=30.0, human_heights=[1.7, 1.6])
+    for k in range(2):
+        d, fps, rp, rr, dp, lb, bn = dataset.load_robot_motion(os.path.join(t2, f"clip_{k:05d}.pkl"))
+        dataset.validate_motion(d, nq=36)
+        assert fps == 30.0 and np.abs(dp - ref[k]["dof_pos"]).max() < 1e-4 and np.abs(rp - ref[k]["root_pos"]).max() < 1e-4

@@ -499,3 +499,31 @@ def test_motion_stream_templates_are_byte_identical_for_every_clip_length():
     # a dict the template cannot express (an object array) still comes out right
     odd = {"fps": 30, "root_pos": np.zeros((500, 3)), "names": np.array(["a", None], dtype=object)}
     assert b"".join(bytes(memoryview(x).cast("B")) for x in dataset.motion_stream(odd)) == pickle.dumps(odd)
+
+
+def test_dataset_script_folder_walk(tmp_path):
+    """gmr_amd.scripts._walk: the folder walk of scripts/bvh_to_robot_dataset.py:59-72 and scripts/smplx_to_robot_dataset.py:205-227 -- sorted
+    (natsorted) names per folder, the target is the source path with the folder and the extension replaced, existing targets are skipped
+    unless --override, `_stagei` files and the hard-motion lists are left out."""
+    from gmr_amd.scripts._walk import hard_motion_names, natural_key, plan_files
+    src, tgt = str(tmp_path / "in"), str(tmp_path / "out")
+    os.makedirs(os.path.join(src, "sub"))
+    for n in ("walk10.bvh", "walk2.bvh", "notes.txt", os.path.join("sub", "run1.bvh")):
+        open(os.path.join(src, n), "w").close()
+    os.makedirs(tgt)
+    open(os.path.join(tgt, "walk2.pkl"), "w").close()
+    s, t, skipped = plan_files(src, tgt, lambda n: n.endswith(".bvh"), ".bvh", override=False)
+    assert [os.path.relpath(x, src) for x in s] == ["walk10.bvh", os.path.join("sub", "run1.bvh")] and skipped == 1
+    assert [os.path.relpath(x, tgt) for x in t] == ["walk10.pkl", os.path.join("sub", "run1.pkl")]
+    s, _, skipped = plan_files(src, tgt, lambda n: n.endswith(".bvh"), ".bvh", override=True, natural=True)
+    assert [os.path.basename(x) for x in s] == ["walk2.bvh", "walk10.bvh", "run1.bvh"] and skipped == 0
+    assert sorted(["a10", "a9", "b1"], key=natural_key) == ["a9", "a10", "b1"]
+    lst = tmp_path / "0.txt"
+    lst.write_text("header\nMotion: ACCAD/Male2/run_poses.npz, error 3.2\nMotion:  CMU/01/01_01_poses , x\nnothing here\n")
+    assert hard_motion_names([str(lst), str(tmp_path / "missing.txt")]) == ["ACCAD/Male2/run_poses", "CMU/01/01_01_poses"]
+    # the argument parsers take the reference's flags
+    import subprocess, sys
+    for mod in ("gmr_amd.scripts.bvh_to_robot_dataset", "gmr_amd.scripts.smplx_to_robot_dataset"):
+        r = subprocess.run([sys.executable, "-m", mod, "--src_folder", str(tmp_path / "empty"), "--tgt_folder", tgt, "--robot", "unitree_g1", "--override"],
+                           capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0 and "Done." in r.stdout, r.stderr[-500:]
