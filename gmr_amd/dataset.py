@@ -319,13 +319,17 @@ class MotionWriter:
                 w.submit(motions, paths)
         w.written, w.skipped
 
-    ``submit`` returns at once; the motion dicts (row slices of the batch's pinned result arrays, ``motions_from_qpos``) stay
-    alive until their files are closed.  An error in a worker is raised by the next ``submit`` / ``close``."""
+    ``submit`` returns at once while at most ``max_pending`` earlier batches are unwritten, else it waits for the oldest of them:
+    the motion dicts (row slices of the batch's pinned result arrays, ``motions_from_qpos``) stay alive until their files are closed,
+    so a disk slower than the GPU must hold the producer back instead of piling up page-locked batches.  An error in a worker is
+    raised by the next ``submit`` / ``close``."""
 
-    def __init__(self, workers: int = 8, override: bool = False):
+    def __init__(self, workers: int = 8, override: bool = False, max_pending: int = 3):
         from concurrent.futures import ThreadPoolExecutor
         self._pool = ThreadPoolExecutor(max_workers=max(1, int(workers)))
         self._override = override
+        self._max_pending = max(1, int(max_pending))
+        self._batches = []  # one list of futures per submitted batch, oldest first
         self._futures = []
         self.written = 0
         self.skipped = 0
@@ -347,8 +351,14 @@ class MotionWriter:
         if len(motions) != len(paths):
             raise ValueError("one path per motion")
         self._reap(False)
-        for m, p in zip(motions, paths):
-            self._futures.append(self._pool.submit(save_motion, p, m, self._override))
+        self._batches = [b for b in self._batches if not all(f.done() for f in b)]
+        while len(self._batches) >= self._max_pending:   # back-pressure: wait for the oldest unwritten batch
+            for f in self._batches.pop(0):
+                f.exception()  # (waits; the error itself is raised by _reap below)
+            self._reap(False)
+        fs = [self._pool.submit(save_motion, p, m, self._override) for m, p in zip(motions, paths)]
+        self._futures += fs
+        self._batches.append(fs)
 
     def close(self) -> None:
         try:

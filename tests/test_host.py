@@ -527,3 +527,31 @@ def test_dataset_script_folder_walk(tmp_path):
         r = subprocess.run([sys.executable, "-m", mod, "--src_folder", str(tmp_path / "empty"), "--tgt_folder", tgt, "--robot", "unitree_g1", "--override"],
                            capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0 and "Done." in r.stdout, r.stderr[-500:]
+
+
+def test_motion_writer_back_pressure(tmp_path, monkeypatch):
+    """MotionWriter.submit waits once ``max_pending`` batches are unwritten (their pinned result arrays stay alive until then): with a
+    writer slowed down artificially, the number of batches in flight never exceeds the bound, and everything is written in the end."""
+    import threading
+    import time
+    from gmr_amd import dataset
+    in_flight, peak, lock = set(), [0], threading.Lock()
+    real = dataset.save_motion
+
+    def slow(path, motion, override=False):
+        with lock:
+            in_flight.add(motion["batch"])
+            peak[0] = max(peak[0], len(in_flight))
+        time.sleep(0.01)
+        r = real(path, {k: v for k, v in motion.items() if k != "batch"}, override)
+        return r
+    monkeypatch.setattr(dataset, "save_motion", slow)
+    done_batches = []
+    with dataset.MotionWriter(workers=2, max_pending=2) as w:
+        for b in range(6):
+            ms = [{"fps": 30, "root_pos": np.zeros((4, 3)), "batch": b} for _ in range(4)]
+            w.submit(ms, [str(tmp_path / f"b{b}_{i}.pkl") for i in range(4)])
+            with lock:   # batches older than the two most recent ones must be complete by now
+                in_flight.intersection_update({b, b - 1})
+            done_batches.append(b)
+    assert w.written == 24 and peak[0] <= 3 and len(list(tmp_path.iterdir())) == 24
