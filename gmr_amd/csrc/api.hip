@@ -1652,7 +1652,8 @@ int gmr_bvh_parse_header(const char *text, size_t len, int max_joints, char *nam
       !frame_time_out || !motion_offset_out)
     return -1;
   gmr_bvh::Cursor c{text, text + len};
-  gmr_bvh::Header h{max_joints, names_out, names_cap};
+  gmr_bvh::Header h{};
+  h.max_joints = max_joints; h.names = names_out; h.names_cap = names_cap;
   h.parents = parents_out; h.offsets = offsets_out; h.channels = channels_out;
   if (!c.next() || !c.is("HIERARCHY") || !c.next() || !c.is("ROOT")) return -1;
   int rc = gmr_bvh::joint(c, h, -1, 0);
