@@ -19,17 +19,24 @@ def main(argv=None) -> int:
     ap.add_argument("--target_fps", default=30, type=int, help="(accepted like the reference, which stores 30 whatever it is given)")
     ap.add_argument("--batch_files", default=64, type=int, help="files per GPU batch (one skeleton per batch)")
     ap.add_argument("--threads", default=8, type=int, help="host threads reading files / writing pickles")
-    ap.add_argument("--device", default=0, type=int)
+    ap.add_argument("--device", default=None, type=int, help="GPU to use (default: LOCAL_RANK under torch.distributed.run, else 0)")
+    ap.add_argument("--shard_by_rank", default=False, action="store_true", help="under torch.distributed.run: convert files[RANK::WORLD_SIZE] only (no exchange between ranks)")
     args = ap.parse_args(argv)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if args.device is None:
+        args.device = int(os.environ.get("LOCAL_RANK", "0"))
     from ._walk import plan_files
     srcs, tgts, skipped = plan_files(args.src_folder, args.tgt_folder, lambda n: n.endswith(".bvh"), ".bvh", args.override)
     print(f"{len(srcs)} files to retarget ({skipped} skipped: target exists)")
+    if args.shard_by_rank and world > 1:
+        srcs, tgts = srcs[rank::world], tgts[rank::world]
+        print(f"rank {rank} of {world}: {len(srcs)} of them")
     if not srcs:
         print("Done. saved to ", args.tgt_folder)
         return 0
     from .. import GeneralMotionRetargeting as GMR, dataset
     from ..bvh import iter_lafan1_batches
-    g = GMR(src_human="bvh", tgt_robot=args.robot)
+    g = GMR(src_human="bvh", tgt_robot=args.robot, device=args.device)
     target_of = dict(zip(srcs, tgts))
     failed = 0
     with dataset.MotionWriter(workers=max(1, args.threads), override=True) as writer:

@@ -23,8 +23,12 @@ def main(argv=None) -> int:
     ap.add_argument("--num_cpus", default=4, type=int, help="host threads reading files / writing pickles (the reference's worker processes)")
     ap.add_argument("--hard_motions", nargs="*", default=None, help="lists of motions to leave out (default: $GMR_ROOT/assets/hard_motions/0.txt, 1.txt when present)")
     ap.add_argument("--batch_files", default=1024, type=int)
-    ap.add_argument("--device", default=0, type=int)
+    ap.add_argument("--device", default=None, type=int, help="GPU to use (default: LOCAL_RANK under torch.distributed.run, else 0)")
+    ap.add_argument("--shard_by_rank", default=False, action="store_true", help="under torch.distributed.run: convert files[RANK::WORLD_SIZE] only (no exchange between ranks)")
     args = ap.parse_args(argv)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if args.device is None:
+        args.device = int(os.environ.get("LOCAL_RANK", "0"))
     from ._walk import hard_motion_names, plan_files
     srcs, tgts, skipped = plan_files(args.src_folder, args.tgt_folder, lambda n: n.endswith(".npz") and not n.endswith("_stagei.npz"), ".npz", args.override, natural=True)
     print("full args_list:", len(srcs))
@@ -41,12 +45,15 @@ def main(argv=None) -> int:
         keep.append((s, t))
     print("new args_list:", len(keep))
     print(f"Total number of files to process: {len(keep)}")
+    if args.shard_by_rank and world > 1:
+        keep = keep[rank::world]
+        print(f"rank {rank} of {world}: {len(keep)} of them")
     if not keep:
         print("Done. Saved to ", args.tgt_folder)
         return 0
     from .. import GeneralMotionRetargeting as GMR, dataset
     from ..smplx_adapter import iter_joint_batches
-    g = GMR(src_human="smplx", tgt_robot=args.robot)
+    g = GMR(src_human="smplx", tgt_robot=args.robot, device=args.device)
     target_of = dict(keep)
     failed = 0
     with dataset.MotionWriter(workers=max(1, args.num_cpus), override=True) as writer:

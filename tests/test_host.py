@@ -527,6 +527,11 @@ def test_dataset_script_folder_walk(tmp_path):
         r = subprocess.run([sys.executable, "-m", mod, "--src_folder", str(tmp_path / "empty"), "--tgt_folder", tgt, "--robot", "unitree_g1", "--override"],
                            capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0 and "Done." in r.stdout, r.stderr[-500:]
+    # --shard_by_rank under torch.distributed.run: rank 1 of 2 takes files[1::2] of the walk -- of the three files that is one
+    env = dict(os.environ, RANK="1", WORLD_SIZE="2", LOCAL_RANK="1")
+    r = subprocess.run([sys.executable, "-m", "gmr_amd.scripts.bvh_to_robot_dataset", "--src_folder", src, "--tgt_folder", str(tmp_path / "o2"), "--shard_by_rank", "--help"],
+                       capture_output=True, text=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "--shard_by_rank" in r.stdout
 
 
 def test_motion_writer_back_pressure(tmp_path, monkeypatch):
