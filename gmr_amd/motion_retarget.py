@@ -370,6 +370,7 @@ class GeneralMotionRetargeting:
         else:
             items = make_items(offs, chunk=chunk, burn_in=burn_in, height_scales=hs, clip_init=clip_init)
             out, iters, _ = self._engine.ik_solve(tpos, tquat, cols, items, params=self._params(offset_to_ground))
+            self.last_chunk_info = {"chunks": len(items), "passes": 0, "resolved_frames": 0}
         if check and N > 0:
             bad = torch.stack([(iters >> 31).ne(0).any(), ((iters >> 30) & 1).ne(0).any()]).cpu().numpy()  # flag bits of the solve counts
             if bad[0]:

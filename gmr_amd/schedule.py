@@ -70,11 +70,19 @@ def auto_chunk(seq_offsets: Sequence[int], slots: int = 2048):
     slots): the launch lasts as long as ONE chunk with its burn-in, the walk as long as the chunk boundaries of the longest clip
     take one after the other -- short chunks for short clips, ~sqrt(longest clip) / 2.  Many frames: chunks queue for slots, the launch
     lasts as long as the work, and every burn-in frame is redundant work -- long chunks, about two per slot.  A burn-in of 24 frames
-    verified as often as 32 on every set and costs a quarter less."""
+    verified as often as 32 on every set and costs a quarter less.  (0, 0) = do not chunk: more than one clip per four slots."""
     offs = np.asarray(seq_offsets, dtype=np.int64)
     lens = np.diff(offs)
     if lens.size == 0 or int(lens.max(initial=0)) == 0:
         return 16, 24
+    if 4 * lens.size > slots:
+        # More than a clip per four wavefront slots: whole clips.  Cutting can gain at most slots / clips (the idle part of the chip) and
+        # only if the chunks verify; clips that do not (targets out of reach, wound-up starts) are re-solved by their walk one after the
+        # other, and then the burn-in frames and the second launch are pure loss -- measured on distinct 3000-frame clips, half of them
+        # noisy / over-reaching: 256 / 1024 / 2048 / 4096 / 8192 clips whole 234 / 275 / 282 / 413 / 611 ms, in chunks 238-253 / 291-317 /
+        # 375-397 / 536-568 / 725-880 ms (tools/experiments/auto_chunk_threshold.py, profiles/r03_unshaped_breakdown.md).  Below the
+        # threshold the possible gain (4x and more: a LAFAN1-sized set of 77 long clips runs 16x faster in chunks) outweighs that loss.
+        return 0, 0
     n, longest = int(lens.sum()), int(lens.max())
     c_latency = 8 * int(round(np.sqrt(longest) / 16.0))
     c_fill = 8 * int(round(n / (2.0 * slots) / 8.0))

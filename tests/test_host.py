@@ -455,7 +455,8 @@ def test_auto_chunk_regimes():
     for wavefront slots (every burn-in frame is redundant work); always inside [16, 128], burn-in 24; degenerate inputs."""
     from gmr_amd.schedule import auto_chunk, make_items
     assert auto_chunk([0, 3000]) == (24, 24) and auto_chunk(np.arange(25) * 4000) == (32, 24) and auto_chunk(np.arange(5) * 9000) == (48, 24)
-    assert auto_chunk(np.arange(78) * 5300)[0] in (96, 104) and auto_chunk(np.arange(8193) * 3000) == (128, 24)
+    assert auto_chunk(np.arange(78) * 5300)[0] in (96, 104) and auto_chunk(np.arange(513) * 30000) == (128, 24)
+    assert auto_chunk(np.arange(8193) * 3000) == (0, 0) and auto_chunk(np.arange(514) * 300) == (0, 0)   # more than a clip per four slots: whole clips
     assert auto_chunk([0]) == (16, 24) and auto_chunk([0, 0, 0]) == (16, 24) and auto_chunk([0, 5]) == (16, 24)
     assert auto_chunk(np.arange(78) * 5300, slots=8 * 2048)[0] == 40      # eight GPUs: the same set no longer fills the slots
     c, b = auto_chunk([0, 100, 100, 7000])
