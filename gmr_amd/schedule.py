@@ -77,7 +77,7 @@ def auto_chunk(seq_offsets: Sequence[int], slots: int = 2048):
         return 16, 24
     if 4 * lens.size > slots:
         # More than a clip per four wavefront slots: whole clips.  Cutting can gain at most slots / clips (the idle part of the chip) and
-        # only if the chunks verify; clips that do not (targets out of reach, wound-up starts) are re-solved by their walk one after the
+        # only if the chunks verify; clips that do not (wound-up starts: a few per cent of distinct clips, whatever the burn-in) are re-solved by their walk one after the
         # other, and then the burn-in frames and the second launch are pure loss -- measured on distinct 3000-frame clips, half of them
         # noisy / over-reaching: 256 / 1024 / 2048 / 4096 / 8192 clips whole 234 / 275 / 282 / 413 / 611 ms, in chunks 238-253 / 291-317 /
         # 375-397 / 536-568 / 725-880 ms (tools/experiments/auto_chunk_threshold.py, profiles/r03_unshaped_breakdown.md).  Below the
