@@ -81,14 +81,15 @@ def motions_from_qpos(gmr: GeneralMotionRetargeting, qpos: torch.Tensor, seq_off
 
 def retarget_clips(gmr: GeneralMotionRetargeting, pos, quat, body_names: Sequence[str], seq_offsets: Sequence[int], fps=30,
                    height_adjust: bool = True, root_origin_offset: bool = True, chunk: int = 0, burn_in: int = 0,
-                   human_heights: Optional[Sequence[float]] = None) -> List[Dict]:
+                   human_heights: Optional[Sequence[float]] = None, clip_start: str = "qpos0") -> List[Dict]:
     """The whole ``process_file`` compute path for a batch of clips: batched IK, FK, post-processing.  ``human_heights``:
     one ``actual_human_height`` per clip (the per-file ``GMR(..., actual_human_height=...)`` of
-    scripts/smplx_to_robot_dataset.py:79-83)."""
+    scripts/smplx_to_robot_dataset.py:79-83).  ``clip_start``: ``retarget_batch``'s (``"root_target"`` is the opt-in departure
+    from the reference that spares wound-up clips their slow start)."""
     tpos = torch.from_numpy(np.ascontiguousarray(pos)) if isinstance(pos, np.ndarray) else pos
     tquat = torch.from_numpy(np.ascontiguousarray(quat)) if isinstance(quat, np.ndarray) else quat
     qpos = gmr.retarget_batch(tpos.to(gmr.device), tquat.to(gmr.device), body_names, seq_offsets=seq_offsets, chunk=chunk, burn_in=burn_in,
-                              human_heights=human_heights)  # (raises on non-finite qpos / a capped QP)
+                              human_heights=human_heights, clip_start=clip_start)  # (raises on non-finite qpos / a capped QP)
     return motions_from_qpos(gmr, qpos, seq_offsets, fps, height_adjust=height_adjust, root_origin_offset=root_origin_offset)
 
 

@@ -20,6 +20,8 @@ def main(argv=None) -> int:
     ap.add_argument("--batch_files", default=64, type=int, help="files per GPU batch (one skeleton per batch)")
     ap.add_argument("--threads", default=8, type=int, help="host threads reading files / writing pickles")
     ap.add_argument("--device", default=None, type=int, help="GPU to use (default: LOCAL_RANK under torch.distributed.run, else 0)")
+    ap.add_argument("--clip_start", default="qpos0", choices=["qpos0", "root_target"],
+                    help="qpos0: the reference (every clip starts from the model's rest pose); root_target: start with the floating base on the first root target (not the reference's numbers for the first frames; spares clips that face away from qpos0 their slow start)")
     ap.add_argument("--shard_by_rank", default=False, action="store_true", help="under torch.distributed.run: convert files[RANK::WORLD_SIZE] only (no exchange between ranks)")
     args = ap.parse_args(argv)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -53,7 +55,7 @@ def main(argv=None) -> int:
                 if not len(batch):
                     continue
                 motions = dataset.retarget_clips(g, batch.pos, batch.quat, batch.body_names, batch.seq_offsets, fps=30, height_adjust=False,   # :127-128
-                                                 root_origin_offset=False, chunk="auto", human_heights=batch.human_heights)
+                                                 root_origin_offset=False, chunk="auto", human_heights=batch.human_heights, clip_start=args.clip_start)
                 writer.submit(motions, [target_of[f] for f in batch.files])
             todo = again if len(again) < len(todo) else []
     print(f"{writer.written} files written, {failed} could not be loaded")

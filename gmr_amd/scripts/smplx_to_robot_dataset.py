@@ -24,6 +24,8 @@ def main(argv=None) -> int:
     ap.add_argument("--hard_motions", nargs="*", default=None, help="lists of motions to leave out (default: $GMR_ROOT/assets/hard_motions/0.txt, 1.txt when present)")
     ap.add_argument("--batch_files", default=1024, type=int)
     ap.add_argument("--device", default=None, type=int, help="GPU to use (default: LOCAL_RANK under torch.distributed.run, else 0)")
+    ap.add_argument("--clip_start", default="qpos0", choices=["qpos0", "root_target"],
+                    help="qpos0: the reference (every clip starts from the model's rest pose); root_target: start with the floating base on the first root target (not the reference's numbers for the first frames; spares clips that face away from qpos0 their slow start)")
     ap.add_argument("--shard_by_rank", default=False, action="store_true", help="under torch.distributed.run: convert files[RANK::WORLD_SIZE] only (no exchange between ranks)")
     args = ap.parse_args(argv)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -64,7 +66,7 @@ def main(argv=None) -> int:
                 failed += 1
             if not len(batch):
                 continue
-            motions = dataset.retarget_clips(g, batch.pos, batch.quat, batch.body_names, batch.seq_offsets, fps=batch.fps, human_heights=batch.human_heights)  # :97-141
+            motions = dataset.retarget_clips(g, batch.pos, batch.quat, batch.body_names, batch.seq_offsets, fps=batch.fps, human_heights=batch.human_heights, clip_start=args.clip_start)  # :97-141
             writer.submit(motions, [target_of[f] for f in batch.files])
     print(f"{writer.written} files written, {failed} could not be loaded")
     print("Done. Saved to ", args.tgt_folder)
