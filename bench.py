@@ -16,7 +16,9 @@ One JSON line on stdout (rank 0).  Besides the driver's contract it carries
   roofline        dominant kernel (ik_kernel) vs the bound that binds it, FP64 vector issue: SURVEY 8(d)'s flop per solve x
                   measured solves, over the kernel time from HIP events; `hbm` is the same kernel against the HBM roofline
                   (north_star asks for it; ~0.3 % by construction, not the bound)
-  fk, dataset_path, host_fed, single_clip, long_clips, live_session   the other kernels / modes of the path (N = 1)
+  fk (+ kin_ops), adapters, dataset_path (+ from_joint_files), host_fed, single_clip, long_clips (+ from_files), heterogeneous,
+  live_session (+ class_api)                                          the other kernels / modes of the path (N = 1), each kernel
+                                                                      against its roofline with PMC traffic where a child pass measures it
   collectives, strong, long_clips_sharded                             N > 1: RCCL exchange steps timed on the real outputs
   cpu_baseline    oracle/ (float64 C restatement of the reference algorithm) timed on this host's cores
   parity          max |qpos_gpu - qpos_cpu| on the clips the CPU leg solved (both workloads)
