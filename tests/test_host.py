@@ -561,3 +561,19 @@ def test_motion_writer_back_pressure(tmp_path, monkeypatch):
                 in_flight.intersection_update({b, b - 1})
             done_batches.append(b)
     assert w.written == 24 and peak[0] <= 3 and len(list(tmp_path.iterdir())) == 24
+
+
+def test_smoke_test_twin(tmp_path):
+    """python -m gmr_amd.scripts.smoke_test: the motion-file checks of scripts/smoke_test.py:19-72 (keys, shapes, hinge count, frames;
+    suspect quaternion norms only warn, as there)."""
+    import pickle
+    from gmr_amd.scripts import smoke_test
+    T = 5
+    good = {"fps": 30, "root_pos": np.zeros((T, 3)), "root_rot": np.tile([0, 0, 0, 1.0], (T, 1)), "dof_pos": np.zeros((T, 29)), "local_body_pos": None, "link_body_list": None}
+    pickle.dump(good, open(tmp_path / "a.pkl", "wb"))
+    pickle.dump(dict(good, root_rot=np.zeros((T, 4))), open(tmp_path / "b_norms.pkl", "wb"))
+    assert smoke_test.main(["--folder", str(tmp_path), "--robot", "unitree_g1"]) == 0
+    pickle.dump({k: v for k, v in good.items() if k != "dof_pos"}, open(tmp_path / "c_missing.pkl", "wb"))
+    pickle.dump(dict(good, root_pos=np.zeros((T, 2))), open(tmp_path / "d_shape.pkl", "wb"))
+    assert smoke_test.main(["--folder", str(tmp_path), "--robot", "unitree_g1"]) == 1
+    assert smoke_test.main(["--folder", str(tmp_path / "nowhere")]) == 0
