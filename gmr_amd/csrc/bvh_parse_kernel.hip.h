@@ -182,18 +182,22 @@ __global__ void __launch_bounds__(64) bvh_txt_parse_kernel(const unsigned char *
   }
   int total;
   int64_t t = bases[chunk] + wave_excl_scan(n, lane, &total);  // index (in its file) of this lane's first token
-  if (!live || n == 0 || t >= limit) return;
+  if (!live || n == 0 || t > limit) return;   // (t == limit: the first token behind the rows asked for still has to START a line, below)
   int64_t col = t % n_cols;
 
   const double p10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
   int i = 0;
   bool pw = prev_ws;
-  while (i < kTxtSpan && n > 0 && t < limit) {
+  while (i < kTxtSpan && n > 0 && t <= limit) {
     const unsigned c0 = byte_at(i);
     if (c0 == '\n') nl_pending = true;
     const bool ws0 = txt_ws(c0);
     if (ws0 || !pw) { pw = ws0; ++i; continue; }
     // a token starts at byte i
+    if (t == limit) {  // nothing behind the last row is read -- but a token on the SAME line makes that row longer than n_cols (the host: -1)
+      if (!nl_pending) atomicOr(&files[f].status, 1);
+      break;
+    }
     if ((col == 0) != nl_pending) atomicOr(&files[f].status, 1);
     nl_pending = false;
     const int start = i;

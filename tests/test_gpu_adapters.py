@@ -325,6 +325,11 @@ def test_device_motion_parser_structure_and_slow_path():
     for bad in (b"1 2 3\n4 5\n6 7 8 9\n", b"1 2\n3 4 5 6\n7 8 9\n", b"1 2 3 4 5 6\n7 8 9\n"):
         rc, rows, status, *_ = _device_parse(lib, dev, bad, [(0, len(bad))], [3 if bad.count(b"\n") == 3 else 2], 3)
         assert rc == 0 and status[0] & 1, bad              # ragged rows: the host parser is asked
+    # ... also when only the LAST row asked for is too long (nothing behind it is read, but its extra tokens make the host parser refuse the
+    # file; found by tools/experiments/hostile_text_only.py), while extra ROWS behind it are fine
+    for blob2, n_lines2, bad2 in ((b"1 2 3\n4 5 6 7\n", 2, True), (b"1 2 3 4\n", 1, True), (b"1 2 3\n4 5 6\n7 8 9\n", 2, False), (b"1 2 3\n4 5 6\n\n  \n7\n", 2, False)):
+        rc, rows, status, *_ = _device_parse(lib, dev, blob2, [(0, len(blob2))], [n_lines2], 3)
+        assert rc == 0 and bool(status[0] & 1) == bad2, (blob2, status)
     # tokens the device must not decide: reported, in order of their place
     odd = b"1e400 nan 0.1234567890123456789012 12345678901234567890 -inf 1_0 abc 1e 0x10 +.5 5. .e1 1.5e+3 -0 1e-30 9007199254740993\n"
     toks = odd.split()
