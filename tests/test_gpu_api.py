@@ -243,9 +243,11 @@ def test_dataset_path_matches_reference_postprocessing(tmp_path):
     assert np.abs(bvh[0]["root_pos"] - q_ref[:50, :3]).max() < 1e-6
 
 
-@pytest.mark.parametrize("name", ["bvh_canonical_40f", "bvh_lafan_like", "bvh_pruned_mid_24f", "bvh_nine_channel"])
+@pytest.mark.parametrize("name", ["bvh_canonical_40f", "bvh_lafan_like", "bvh_pruned_mid_24f", "bvh_nine_channel"] + [f"bvh_random_{k}" for k in range(6)])
 def test_bvh_adapter_matches_reference_loader(name, golden_dir):
-    """gmr_amd.bvh.load_lafan1_file (host parse + gmr_bvh_fk) vs the reference's load_lafan1_file output (golden)."""
+    """gmr_amd.bvh.load_lafan1_file (host parse + gmr_bvh_fk) vs the reference's load_lafan1_file output (golden).  bvh_random_<k>
+    (tests/golden/make_bvh_golden_random.py): random trees in the Euler orders XYZ, YZX, ZXY, XZY, YXZ, ZYX and all three row layouts, with
+    and without the bone names the loader treats specially."""
     from gmr_amd.bvh import load_lafan1_file
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     clip = load_lafan1_file(os.path.join(golden_dir, name + ".bvh"))
