@@ -4,9 +4,11 @@
 ``from general_motion_retargeting import GeneralMotionRetargeting as GMR``.
 Heavy imports (torch, the native library) happen on first attribute access.
 """
-from .params import IK_CONFIG_DICT, IK_CONFIG_ROOT, ROBOT_BASE_DICT, ROBOT_XML_DICT  # noqa: F401
+from .params import ASSET_ROOT, IK_CONFIG_DICT, IK_CONFIG_ROOT, ROBOT_BASE_DICT, ROBOT_XML_DICT, VIEWER_CAM_DISTANCE_DICT  # noqa: F401
 
-__all__ = ["GeneralMotionRetargeting", "KinematicsModel", "ROBOT_XML_DICT", "IK_CONFIG_DICT", "ROBOT_BASE_DICT", "IK_CONFIG_ROOT"]
+# the names general_motion_retargeting/__init__.py:2-6 exports (RobotMotionViewer is out of scope: asking for it says so)
+__all__ = ["GeneralMotionRetargeting", "KinematicsModel", "load_robot_motion", "ROBOT_XML_DICT", "IK_CONFIG_DICT", "ROBOT_BASE_DICT", "IK_CONFIG_ROOT",
+           "ASSET_ROOT", "VIEWER_CAM_DISTANCE_DICT"]
 
 
 def __getattr__(name):
@@ -16,4 +18,9 @@ def __getattr__(name):
     if name == "KinematicsModel":
         from .kinematics_model import KinematicsModel
         return KinematicsModel
+    if name == "load_robot_motion":
+        from .dataset import load_robot_motion
+        return load_robot_motion
+    if name == "RobotMotionViewer":
+        raise AttributeError("gmr_amd has no RobotMotionViewer: the MuJoCo viewer is outside this engine's scope (use the reference's with the qpos this engine returns)")
     raise AttributeError(name)

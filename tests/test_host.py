@@ -577,3 +577,20 @@ def test_smoke_test_twin(tmp_path):
     pickle.dump(dict(good, root_pos=np.zeros((T, 2))), open(tmp_path / "d_shape.pkl", "wb"))
     assert smoke_test.main(["--folder", str(tmp_path), "--robot", "unitree_g1"]) == 1
     assert smoke_test.main(["--folder", str(tmp_path / "nowhere")]) == 0
+
+
+def test_package_exports_the_reference_package_names(monkeypatch):
+    """general_motion_retargeting/__init__.py:2-6 exports the registry dicts, the two classes and load_robot_motion: code written as
+    `from general_motion_retargeting import X` finds every X here but the viewer, which says why it is missing."""
+    import importlib
+    import gmr_amd
+    for name in ("IK_CONFIG_ROOT", "ASSET_ROOT", "ROBOT_XML_DICT", "IK_CONFIG_DICT", "ROBOT_BASE_DICT", "VIEWER_CAM_DISTANCE_DICT", "load_robot_motion"):
+        assert getattr(gmr_amd, name) is not None, name
+    assert set(gmr_amd.VIEWER_CAM_DISTANCE_DICT) == set(gmr_amd.ROBOT_XML_DICT.keys()) == set(gmr_amd.ROBOT_BASE_DICT)
+    with pytest.raises(AttributeError, match="viewer"):
+        gmr_amd.RobotMotionViewer
+    root = os.environ.get("GMR_ROOT") or "/root/reference"
+    if os.path.isdir(os.path.join(root, "assets")):   # (the build container: ASSET_ROOT follows GMR_ROOT like the registry paths)
+        monkeypatch.setenv("GMR_ROOT", root)
+        from gmr_amd import params
+        assert str(params.asset_root()) == os.path.join(root, "assets")
