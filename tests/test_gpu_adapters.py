@@ -575,3 +575,43 @@ def test_dataset_script_twins_end_to_end(golden_dir, tmp_path, capsys):
         d, fps, rp, rr, dp, lb, bn = dataset.load_robot_motion(os.path.join(t2, f"clip_{k:05d}.pkl"))
         dataset.validate_motion(d, nq=36)
         assert fps == 30.0 and np.abs(dp - ref[k]["dof_pos"]).max() < 1e-4 and np.abs(rp - ref[k]["root_pos"]).max() < 1e-4
+
+
+def test_utils_modules_keep_the_reference_signatures(golden_dir):
+    """gmr_amd.utils.lafan1.load_lafan1_file / gmr_amd.utils.smpl.get_smplx_data_offline_fast: the import paths, arguments and return shapes of
+    general_motion_retargeting.utils (lafan1.py:8-71, smpl.py:109-198) -- a list of per-frame dicts {name: (position, quaternion wxyz)} plus the
+    height / the aligned frame rate -- so that a script keeps its loops; values against the reference loader's golden and the scipy restatement."""
+    import os
+    from types import SimpleNamespace
+    from gmr_amd.smplx_adapter import SMPLX_JOINT_NAMES, SMPLX_PARENTS
+    from gmr_amd.utils.lafan1 import load_lafan1_file
+    from gmr_amd.utils.smpl import get_smplx_data_offline_fast, load_smplx_file
+    g = np.load(os.path.join(golden_dir, "bvh_lafan_like.npz"))
+    frames, height = load_lafan1_file(os.path.join(golden_dir, "bvh_lafan_like.bvh"))
+    assert isinstance(frames, list) and len(frames) == g["pos"].shape[0] and list(frames[0].keys()) == [str(n) for n in g["names"]]
+    assert abs(height - float(g["human_height"])) < 1e-9
+    for t in (0, len(frames) - 1):
+        for i, n in enumerate(frames[t]):
+            p, q = frames[t][n]
+            assert p.shape == (3,) and q.shape == (4,) and np.abs(p - g["pos"][t, i]).max() < 1e-9
+            assert min(np.abs(q - g["quat"][t, i]).max(), np.abs(q + g["quat"][t, i]).max()) < 1e-9
+    # SMPL-X: what load_smplx_file hands over, faked (float32 torch tensors as the body model emits them)
+    rng = np.random.default_rng(4)
+    for T, fps, tgt in ((120, 120.0, 30), (40, 30.0, 30)):
+        fp = (rng.normal(0, 0.4, (1, 55, 3)) + np.cumsum(rng.normal(0, 0.02, (T, 55, 3)), axis=0)).astype(np.float32)
+        jt = (rng.normal(0, 0.5, (1, 127, 3)) + np.cumsum(rng.normal(0, 0.01, (T, 127, 3)), axis=0)).astype(np.float32)
+        data = {"mocap_frame_rate": np.array(fps), "pose_body": np.zeros((T, 63))}
+        model = SimpleNamespace(parents=torch.tensor(SMPLX_PARENTS))
+        out = SimpleNamespace(global_orient=torch.from_numpy(fp[:, 0].copy()), full_pose=torch.from_numpy(fp.reshape(T, 165)), joints=torch.from_numpy(jt))
+        fr, afps = get_smplx_data_offline_fast(data, model, out, tgt_fps=tgt)
+        resample = tgt < fps
+        T_out = T // int(fps / tgt) if resample else T
+        assert len(fr) == T_out and list(fr[0].keys()) == SMPLX_JOINT_NAMES
+        assert (afps == T_out / T * fps) if resample else (afps is tgt)
+        p_ref, q_ref = _smplx_restatement(fp[:, 0].astype(np.float64), fp.astype(np.float64), jt.astype(np.float64), np.asarray(SMPLX_PARENTS, np.int32), T_out, resample)
+        for t in (0, T_out - 1):
+            for i, n in enumerate(SMPLX_JOINT_NAMES):
+                p, q = fr[t][n]
+                assert np.abs(p - p_ref[t, i]).max() < 1e-12 and min(np.abs(q - q_ref[t, i]).max(), np.abs(q + q_ref[t, i]).max()) < 1e-10
+    with pytest.raises(ImportError, match="smplx"):
+        load_smplx_file("nothing.npz", "nowhere")
