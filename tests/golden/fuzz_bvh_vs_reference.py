@@ -39,12 +39,15 @@ def fmt(rng, v):
     return ["%.6f" % v, "%.4f" % v, "%d" % round(v), "%.10g" % v, "%.3e" % v][k].replace("e+", "e")   # (no '+', no 'E': the reference's OFFSET regex)
 
 
-def make_file(rng, path):
+def make_file(rng, path, special=()):
+    """``special``: bone names to plant on random non-root joints (the names load_lafan1_file treats specially)."""
     J = int(rng.integers(1, 41))
     parents = [-1] + [int(rng.integers(0, j)) for j in range(1, J)]
     layout = int(rng.choice([3, 6, 9])) if J > 1 else int(rng.choice([3, 6]))
     order = [AX[i] for i in rng.permutation(3)]
     names = ["j%d_%s" % (j, "".join(rng.choice(list("abcXYZ_09"), size=int(rng.integers(0, 5))))) for j in range(J)]
+    for n, j in zip(special, rng.permutation(np.arange(1, J))[: len(special)] if J > 1 else []):
+        names[int(j)] = n
     children = {j: [c for c in range(J) if parents[c] == j] for j in range(J)}
     # the reference numbers joints in file order = depth-first order of the text: emit recursively and record that order
     file_order, lines = [], ["HIERARCHY"]
