@@ -7,7 +7,7 @@ Run in the build container only (needs /root/reference; never on the GPU box):
 
     python tests/golden/fuzz_fk_vs_reference.py [seconds] [seed]
 
-Same import recipe as make_golden.py.  Robots: the five the reference class can parse.  Inputs per draw: 1-4096 frames, joint angles up
+Same import recipe as make_golden.py.  Robots: the eight of the registry's eleven the reference class can parse.  Inputs per draw: 1-4096 frames, joint angles up
 to +-8 rad, root positions up to +-50 m, unit and non-unit root quaternions, random / tiny / near-pi joint rotations, body scales 0.5-2.
 """
 import os
@@ -30,7 +30,8 @@ from oracle.oracle import Oracle  # noqa: E402
 from tests.util import compiled  # noqa: E402
 
 ROBOTS = {"unitree_g1": "unitree_g1/g1_mocap_29dof.xml", "unitree_g1_with_hands": "unitree_g1/g1_mocap_29dof_with_hands.xml", "booster_t1": "booster_t1/t1_mocap.xml",
-          "stanford_toddy": "stanford_toddy/toddy_mocap.xml", "fourier_n1": "fourier_n1/n1_mocap.xml"}
+          "stanford_toddy": "stanford_toddy/toddy_mocap.xml", "fourier_n1": "fourier_n1/n1_mocap.xml", "kuavo_s45": "kuavo_s45/biped_s45_collision.xml",
+          "hightorque_hi": "hightorque_hi/hi_25dof.xml", "booster_k1": "booster_k1/K1_serial.xml"}
 
 
 def main():
@@ -78,7 +79,7 @@ def main():
         worst["fitted_shape"] = max(worst["fitted_shape"], float(np.abs(bps - bps_r.numpy()).max()) / max(1.0, float(bps_r.abs().max())))
         runs += 1
         frames += n
-    print(f"oracle float32 KinematicsModel restatements vs the reference's class: {runs} draws, {frames} frames, 5 robots, {time.time() - t0:.0f} s; worst difference "
+    print(f"oracle float32 KinematicsModel restatements vs the reference's class: {runs} draws, {frames} frames, {len(ROBOTS)} robots, {time.time() - t0:.0f} s; worst difference "
           + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()) + " (positions / rotations relative to the largest magnitude in play; bound 2e-6)")
     return 1 if max(worst.values()) > 2e-6 else 0
 

@@ -38,12 +38,18 @@ ROBOTS = {
     "booster_t1": "booster_t1/t1_mocap.xml",
     "stanford_toddy": "stanford_toddy/toddy_mocap.xml",
     "fourier_n1": "fourier_n1/n1_mocap.xml",
+    # (added later; `python <this script> kuavo_s45 hightorque_hi booster_k1` writes only the robots named, leaving the older files untouched)
+    "kuavo_s45": "kuavo_s45/biped_s45_collision.xml",
+    "hightorque_hi": "hightorque_hi/hi_25dof.xml",
+    "booster_k1": "booster_k1/K1_serial.xml",
 }
 
 
 def main():
     T = 64
     for name, rel in ROBOTS.items():
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue
         km = KinematicsModel(os.path.join(REF, "assets", rel), "cpu")
         lo, hi = km.get_dof_limits()
         rng = np.random.default_rng(0)
@@ -67,6 +73,8 @@ def main():
                 "num_dof": km.num_dof,
             }, f)
         print(name, bp.shape, br.shape)
+    if len(sys.argv) > 1:
+        return
     rng = np.random.default_rng(1)
     a = rng.normal(size=(32, 4))
     b = rng.normal(size=(32, 4))

@@ -35,6 +35,10 @@ ROBOTS = {
     "booster_t1": "booster_t1/t1_mocap.xml",
     "stanford_toddy": "stanford_toddy/toddy_mocap.xml",
     "fourier_n1": "fourier_n1/n1_mocap.xml",
+    # (added later; `python <this script> kuavo_s45 hightorque_hi booster_k1` writes only the robots named, leaving the older files untouched)
+    "kuavo_s45": "kuavo_s45/biped_s45_collision.xml",
+    "hightorque_hi": "hightorque_hi/hi_25dof.xml",
+    "booster_k1": "booster_k1/K1_serial.xml",
 }
 
 
@@ -46,6 +50,8 @@ def unit(rng, shape):
 def main():
     T = 40
     for name, rel in ROBOTS.items():
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue
         km = KinematicsModel(os.path.join(REF, "assets", rel), "cpu")
         nb, nd = km.num_joint, km.num_dof
         lo, hi = km.get_dof_limits()

@@ -17,7 +17,9 @@ from gmr_amd import synth
 from oracle.oracle import Oracle, WORK_ITEM_DTYPE, box_qp
 from tests.util import CONFIG_ROBOTS, compiled, make_items, quat_angle
 
-GOLDEN_ROBOTS = ["unitree_g1", "unitree_g1_with_hands", "booster_t1", "stanford_toddy", "fourier_n1"]
+# every registry robot the reference's KinematicsModel can parse (engineai_pm01 needs <include>, galaxea_r1pro and
+# berkeley_humanoid_lite fail in its _parse_xml: no golden possible)
+GOLDEN_ROBOTS = ["unitree_g1", "unitree_g1_with_hands", "booster_t1", "stanford_toddy", "fourier_n1", "kuavo_s45", "hightorque_hi", "booster_k1"]
 
 
 @pytest.mark.parametrize("robot", GOLDEN_ROBOTS)
