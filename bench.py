@@ -335,7 +335,7 @@ def main():
         if torch.isnan(uout).any().item():
             raise SystemExit("non-finite qpos in the un-shaped benchmark output")
         un = {"frames": int(uoffs[-1]), "elapsed": u_el, "steps": max(1, args.steps - 1), "kern_ms": u_kern_ms, "solves": u_solves, "hist": u_hist,
-              "capped": u_capped, "gen_s": t_gen, "lens": lens}
+              "capped": u_capped, "gen_s": t_gen, "lens": lens, "planned": eng._order_pays(uitems)}
 
     result = None
     if rank == 0:
@@ -393,6 +393,8 @@ def main():
                 "mean_solves_per_frame": un["solves"], "solves_per_frame_histogram": un["hist"], "qp_iteration_caps_hit": un["capped"],
                 "clip_length_min_max": [int(un["lens"].min()), int(un["lens"].max())], "generation_s": un["gen_s"],
                 "valu_frac": un["frames"] / (un["kern_ms"] * 1e-3) * un["solves"] * fsolve / 1e12 / FP64_VECTOR_PEAK_TF,
+                "launch_order": {"planned": bool(un["planned"]), "note": "the default call: a 32-frame probe of every clip, cost = its solves x the clip's length, most expensive first "
+                                                                         "-- probe and sort inside the timed region (729 ms in plain length order, tools/experiments/unshaped_probe_order.py)"},
             }
 
     # ------------------------------------------------------------------ every N: the CPU path in the same run + parity of rank 0's output

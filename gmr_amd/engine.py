@@ -81,8 +81,8 @@ class Engine:
         Frames not covered by any item's output range are left as NaN.  Returns (qpos, iters or None, qpos_final or None).
         ``frames_done`` (int32 [n_items] on the device) receives the output frames each item solved (repair runs, gmr_blob.h).
         ``launch_order``: an int32 device tensor from :meth:`plan_order`, ``None`` (array order, longer items first) or ``"auto"``
-        -- plan an order when that pays: more plain items than wavefront slots and lengths so alike that they say nothing about
-        cost (``PROBE_*`` below).  The order only moves work in time; results are identical.
+        -- plan an order when that pays: more plain items than wavefront slots, long enough for the probe to be a small fraction of
+        the work (``PROBE_*`` below).  The order only moves work in time; results are identical.
         """
         if pos.device != self.device or quat.device != self.device:
             raise EngineError("inputs must live on the engine's device")
@@ -151,13 +151,14 @@ class Engine:
         self.last_stats = stats
         return out, iters, qfin
 
-    # Launch order by predicted cost (gmr_ik_plan_order): when it is worth a probe.  Measured on 8192 x 3000 equal-length clips:
-    # 608 ms in array order, 549 ms ordered by a 32-frame probe (+ 6 ms for the probe); on clips of 1000-5000 frames the length
-    # order gmr_ik_solve applies by itself already is the cost order (725 ms either way).
+    # Launch order by predicted cost (gmr_ik_plan_order: solves of an item's first frames x its length): when it is worth a probe.
+    # Measured on 8192 x 3000 equal-length clips: 608 ms in array order, 549 ms ordered by a 32-frame probe (+ 8 ms for the probe).  On
+    # distinct clips of 1000-5000 frames the length order gmr_ik_solve applies by itself is NOT the cost order either -- a few per cent
+    # of the clips run the full solve budget on most frames (3x the cost of their length) --: 729 ms in length order, 692 ms
+    # in the probe's order, probe included (705 / 703 ms with 16 / 64 probe frames; tools/experiments/unshaped_probe_order.py).
     PROBE_FRAMES = 32
     PROBE_MIN_ITEMS_PER_SLOT = 1.0   # at most one item per wavefront slot: everything starts at once, order is irrelevant
-    PROBE_MAX_LENGTH_SPREAD = 0.10   # coefficient of variation of the item lengths below which lengths carry no cost information
-    PROBE_MIN_LENGTH = 16 * 32       # the probe must stay a small fraction of the work
+    PROBE_MIN_LENGTH = 16 * 32       # mean item length from which the probe is a small fraction of the work
 
     def _order_pays(self, items: np.ndarray) -> bool:
         if len(items) == 0 or np.any(items["check_stride"] != 0):
@@ -166,7 +167,7 @@ class Engine:
         if len(items) <= self.PROBE_MIN_ITEMS_PER_SLOT * slots:
             return False
         ln = (items["n_burn"] + items["n_out"]).astype(np.float64)
-        return bool(ln.min() >= self.PROBE_MIN_LENGTH and ln.std() <= self.PROBE_MAX_LENGTH_SPREAD * ln.mean())
+        return bool(ln.mean() >= self.PROBE_MIN_LENGTH)
 
     def plan_order(self, pos: torch.Tensor, quat: torch.Tensor, slot_col: np.ndarray, items: np.ndarray, params: Optional[IKParams] = None,
                    qpos_init: Optional[torch.Tensor] = None, probe_frames: Optional[int] = None) -> torch.Tensor:

@@ -869,7 +869,7 @@ def test_persistent_session_is_the_batch_solver_fed_frame_by_frame():
 def test_launch_order_by_probe_moves_work_in_time_only():
     """gmr_ik_plan_order / gmr_ik_solve_ordered: the probe's order is a permutation that ranks the expensive clips first, the ordered
     launch gives bit for bit what the plain launch gives (qpos, solve counts, frames_done), and `launch_order="auto"` plans only
-    when there are more equal-length items than wavefront slots."""
+    when there are more items than wavefront slots, long enough for the probe to be a small fraction of the work."""
     from gmr_amd.engine import Engine, EngineError
     cm = compiled("smplx", "unitree_g1")
     eng = Engine(cm)
@@ -894,14 +894,27 @@ def test_launch_order_by_probe_moves_work_in_time_only():
     fd1 = torch.zeros(S, dtype=torch.int32, device=dev)
     q1, it1, _ = eng.ik_solve(pos, quat, sc, items, launch_order=order, frames_done=fd1)
     assert torch.equal(q0, q1) and torch.equal(it0, it1) and torch.equal(fd0, fd1) and int(fd1.min()) == T
-    # "auto": equal lengths and more items than slots -> planned (same result); PROBE_MIN_LENGTH keeps short items out
+    # "auto": more items than slots -> planned (same result), equal lengths or not; PROBE_MIN_LENGTH keeps short items out
     assert not eng._order_pays(items) and eng._order_pays(make_items(np.arange(S + 1, dtype=np.int64) * 600))
-    assert not eng._order_pays(make_items(offs[:1025])) and not eng._order_pays(make_items(np.cumsum(np.r_[0, np.tile([600, 900], S // 2)])))
+    assert not eng._order_pays(make_items(offs[:1025])) and eng._order_pays(make_items(np.cumsum(np.r_[0, np.tile([600, 900], S // 2)])))
     eng.PROBE_MIN_LENGTH = 64
     try:
         assert eng._order_pays(items)
         q2, it2, _ = eng.ik_solve(pos, quat, sc, items)  # launch_order="auto"
         assert torch.equal(q0, q2) and torch.equal(it0, it2)
+    finally:
+        del eng.PROBE_MIN_LENGTH
+    # items of different lengths (the un-shaped workload's case): planned as well, and still the plain launch's numbers
+    lens = np.tile([64, 96, 80, 144], S // 4)
+    voffs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    vitems = make_items(voffs)
+    vpos, vquat = pos[: voffs[-1]].contiguous(), quat[: voffs[-1]].contiguous()
+    qa, ia, _ = eng.ik_solve(vpos, vquat, sc, vitems, launch_order=None)
+    eng.PROBE_MIN_LENGTH = 64
+    try:
+        assert eng._order_pays(vitems)
+        qb, ib, _ = eng.ik_solve(vpos, vquat, sc, vitems)
+        assert torch.equal(qa, qb) and torch.equal(ia, ib)
     finally:
         del eng.PROBE_MIN_LENGTH
     with pytest.raises(EngineError):
