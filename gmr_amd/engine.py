@@ -132,7 +132,8 @@ class Engine:
         if isinstance(launch_order, str):
             if launch_order != "auto":
                 raise EngineError("launch_order must be a tensor, None or 'auto'")
-            launch_order = self.plan_order(pos, quat, slot_col, items, prm, qpos_init) if self._order_pays(items) else None
+            pf = self._probe_frames(items)
+            launch_order = self.plan_order(pos, quat, slot_col, items, prm, qpos_init, probe_frames=pf) if pf else None
         dt = _native.GMR_DTYPE_F64 if pos.dtype == torch.float64 else _native.GMR_DTYPE_F32
         if launch_order is None:
             rc = self._lib.gmr_ik_solve(
@@ -151,23 +152,40 @@ class Engine:
         self.last_stats = stats
         return out, iters, qfin
 
-    # Launch order by predicted cost (gmr_ik_plan_order: solves of an item's first frames x its length): when it is worth a probe.
-    # Measured on 8192 x 3000 equal-length clips: 608 ms in array order, 549 ms ordered by a 32-frame probe (+ 8 ms for the probe).  On
-    # distinct clips of 1000-5000 frames the length order gmr_ik_solve applies by itself is NOT the cost order either -- a few per cent
-    # of the clips run the full solve budget on most frames (3x the cost of their length) --: 729 ms in length order, 692 ms
-    # in the probe's order, probe included (705 / 703 ms with 16 / 64 probe frames; tools/experiments/unshaped_probe_order.py).
+    # Launch order by predicted cost (gmr_ik_plan_order: solves of an item's first frames x its length): when it is worth a probe, and of
+    # how many frames.  Measured on 8192 distinct clips per launch, any heading, probe and device sort included
+    # (tools/experiments/short_clip_probe.py, unshaped_probe_order.py; profiles/r03_unshaped_breakdown.md):
+    #   equal lengths (nothing else tells the clips apart): 100 / 150 / 200 frames 32.4 -> 30.2, 47.9 -> 45.0, 65.3 -> 57.6 ms with a 4-frame probe;
+    #     300 / 600 / 1000 / 3000 frames 94.8 -> 81.5, 183.7 -> 150.3, 306.5 -> 240.9, 608 -> 549 ms with 32 frames;
+    #   lengths U(T/3, 5T/3) (the length order gmr_ik_solve applies by itself is most of the cost order): 300 / 600 frames: any probe loses
+    #     (74.9 -> 78.6+, 147.3 -> 150.0+); 1000 / 1500 / 2000 / 3000 frames: 245.5 -> 243.0, 365.6 -> 351.1, 493.7 -> 470.8, 728.7 -> 691.8 ms with 32
+    #     frames, shorter probes lose -- a few per cent of the clips run the full solve budget on most frames (3 x the cost of their length,
+    #     DESIGN 6) and have to start first, but it takes 32 frames to tell them from the start-up every clip goes through.
     PROBE_FRAMES = 32
+    PROBE_FRAMES_SHORT = 4           # equal-length items of fewer than PROBE_SHORT_BELOW frames
+    PROBE_SHORT_BELOW = 256
     PROBE_MIN_ITEMS_PER_SLOT = 1.0   # at most one item per wavefront slot: everything starts at once, order is irrelevant
-    PROBE_MIN_LENGTH = 16 * 32       # mean item length from which the probe is a small fraction of the work
+    PROBE_MAX_LENGTH_SPREAD = 0.10   # coefficient of variation of the item lengths below which lengths carry no cost information
+    PROBE_MIN_LENGTH_EQUAL = 64      # mean item length from which a probe pays: equal lengths ...
+    PROBE_MIN_LENGTH = 1000          # ... and lengths that differ
 
-    def _order_pays(self, items: np.ndarray) -> bool:
+    def _probe_frames(self, items: np.ndarray) -> int:
+        """Frames of every item to probe before an ``launch_order="auto"`` launch; 0 = launch in length order without a probe."""
         if len(items) == 0 or np.any(items["check_stride"] != 0):
-            return False
+            return 0
         slots = 8 * torch.cuda.get_device_properties(self.device).multi_processor_count  # two wavefronts per SIMD
         if len(items) <= self.PROBE_MIN_ITEMS_PER_SLOT * slots:
-            return False
+            return 0
         ln = (items["n_burn"] + items["n_out"]).astype(np.float64)
-        return bool(ln.mean() >= self.PROBE_MIN_LENGTH)
+        mean = float(ln.mean())
+        if ln.std() <= self.PROBE_MAX_LENGTH_SPREAD * mean:
+            if mean < self.PROBE_MIN_LENGTH_EQUAL:
+                return 0
+            return self.PROBE_FRAMES if mean >= self.PROBE_SHORT_BELOW else self.PROBE_FRAMES_SHORT
+        return self.PROBE_FRAMES if mean >= self.PROBE_MIN_LENGTH else 0
+
+    def _order_pays(self, items: np.ndarray) -> bool:
+        return self._probe_frames(items) > 0
 
     def plan_order(self, pos: torch.Tensor, quat: torch.Tensor, slot_col: np.ndarray, items: np.ndarray, params: Optional[IKParams] = None,
                    qpos_init: Optional[torch.Tensor] = None, probe_frames: Optional[int] = None) -> torch.Tensor:

@@ -894,17 +894,16 @@ def test_launch_order_by_probe_moves_work_in_time_only():
     fd1 = torch.zeros(S, dtype=torch.int32, device=dev)
     q1, it1, _ = eng.ik_solve(pos, quat, sc, items, launch_order=order, frames_done=fd1)
     assert torch.equal(q0, q1) and torch.equal(it0, it1) and torch.equal(fd0, fd1) and int(fd1.min()) == T
-    # "auto": more items than slots -> planned (same result), equal lengths or not; PROBE_MIN_LENGTH keeps short items out
-    assert not eng._order_pays(items) and eng._order_pays(make_items(np.arange(S + 1, dtype=np.int64) * 600))
-    assert not eng._order_pays(make_items(offs[:1025])) and eng._order_pays(make_items(np.cumsum(np.r_[0, np.tile([600, 900], S // 2)])))
-    eng.PROBE_MIN_LENGTH = 64
-    try:
-        assert eng._order_pays(items)
-        q2, it2, _ = eng.ik_solve(pos, quat, sc, items)  # launch_order="auto"
-        assert torch.equal(q0, q2) and torch.equal(it0, it2)
-    finally:
-        del eng.PROBE_MIN_LENGTH
-    # items of different lengths (the un-shaped workload's case): planned as well, and still the plain launch's numbers
+    # "auto" (Engine._probe_frames): more items than slots; equal lengths -> a 4-frame probe from 64 frames on, 32 frames from 256 on;
+    # different lengths -> 32 frames from a mean of 1000 on, no probe below (the length order is better there)
+    eq = lambda n, T_: make_items(np.arange(n + 1, dtype=np.int64) * T_)  # noqa: E731
+    assert eng._probe_frames(items) == 4 and eng._probe_frames(eq(S, 600)) == 32 and eng._probe_frames(eq(S, 255)) == 4 and eng._probe_frames(eq(S, 48)) == 0
+    assert eng._probe_frames(make_items(offs[:1025])) == 0 and not eng._order_pays(eq(2048, 3000))                    # no more items than slots
+    var = lambda a, b: make_items(np.cumsum(np.r_[0, np.tile([a, b], S // 2)]))  # noqa: E731
+    assert eng._probe_frames(var(600, 900)) == 0 and eng._probe_frames(var(800, 1600)) == 32
+    q2, it2, _ = eng.ik_solve(pos, quat, sc, items)  # launch_order="auto": the 96-frame items are probed (4 frames) -- same numbers
+    assert torch.equal(q0, q2) and torch.equal(it0, it2)
+    # items of different lengths (the un-shaped workload's case), forced through the probe: still the plain launch's numbers
     lens = np.tile([64, 96, 80, 144], S // 4)
     voffs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     vitems = make_items(voffs)
@@ -912,7 +911,7 @@ def test_launch_order_by_probe_moves_work_in_time_only():
     qa, ia, _ = eng.ik_solve(vpos, vquat, sc, vitems, launch_order=None)
     eng.PROBE_MIN_LENGTH = 64
     try:
-        assert eng._order_pays(vitems)
+        assert eng._probe_frames(vitems) == 32
         qb, ib, _ = eng.ik_solve(vpos, vquat, sc, vitems)
         assert torch.equal(qa, qb) and torch.equal(ia, ib)
     finally:
