@@ -297,7 +297,7 @@ def main():
     mids = []
 
     def headline_step():  # == eng.ik_solve(pos, quat, sc, items, out=out) with launch_order="auto", an event between its two halves
-        order = eng.plan_order(pos, quat, sc, items) if planned else None
+        order = eng.plan_order(pos, quat, sc, items, probe_frames=eng._probe_frames(items)) if planned else None
         mid = torch.cuda.Event(enable_timing=True)
         mid.record()
         mids.append(mid)
@@ -374,7 +374,7 @@ def main():
                          "kernel": kernel_name, "kernel_ms": kern_ms, "flop_per_solve": fsolve, "mean_solves_per_frame": mean_solves,
                          "solves_per_frame_histogram": solves_hist,
                          "step_ms": step_ms, "frac_of_step": n_frames / (step_ms * 1e-3) * mean_solves * fsolve / 1e12 / FP64_VECTOR_PEAK_TF,
-                         "launch_order": {"planned": bool(planned), "probe_frames": int(eng.PROBE_FRAMES) if planned else 0,
+                         "launch_order": {"planned": bool(planned), "probe_frames": int(eng._probe_frames(items)),
                                           "probe_kernel": kernel_name.replace("ik_kernel", "ik_probe_kernel") + " + gmr::plan_order_kernel",
                                           "probe_ms": probe_ms, "array_order_kernel_ms": array_order_ms,
                                           "note": "equal-length clips differ in cost (solves per frame); every step probes the first frames of "
