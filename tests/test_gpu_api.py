@@ -901,6 +901,7 @@ def test_launch_order_by_probe_moves_work_in_time_only():
     assert eng._probe_frames(make_items(offs[:1025])) == 0 and not eng._order_pays(eq(2048, 3000))                    # no more items than slots
     var = lambda a, b: make_items(np.cumsum(np.r_[0, np.tile([a, b], S // 2)]))  # noqa: E731
     assert eng._probe_frames(var(600, 900)) == 0 and eng._probe_frames(var(800, 1600)) == 32
+    assert eng._probe_frames(make_items(np.arange(65, dtype=np.int64) * 6400, chunk=104, burn_in=24)) == 0           # speculative chunks are not probed
     q2, it2, _ = eng.ik_solve(pos, quat, sc, items)  # launch_order="auto": the 96-frame items are probed (4 frames) -- same numbers
     assert torch.equal(q0, q2) and torch.equal(it0, it2)
     # items of different lengths (the un-shaped workload's case), forced through the probe: still the plain launch's numbers
