@@ -159,7 +159,7 @@ class Engine:
     #     300 / 600 / 1000 / 3000 frames 94.8 -> 81.5, 183.7 -> 150.3, 306.5 -> 240.9, 608 -> 549 ms with 32 frames;
     #   lengths U(T/3, 5T/3) (the length order gmr_ik_solve applies by itself is most of the cost order): 300 / 600 frames: any probe loses
     #     (74.9 -> 78.6+, 147.3 -> 150.0+); 1000 / 1500 / 2000 / 3000 frames: 245.5 -> 243.0, 365.6 -> 351.1, 493.7 -> 470.8, 728.7 -> 691.8 ms with 32
-    #     frames, shorter probes lose -- a few per cent of the clips run the full solve budget on most frames (3 x the cost of their length,
+    #     frames, shorter probes lose -- a few per cent of the clips need ~12 solves per frame against a median of 6.6 (twice the cost of their length,
     #     DESIGN 6) and have to start first, but it takes 32 frames to tell them from the start-up every clip goes through.
     PROBE_FRAMES = 32
     PROBE_FRAMES_SHORT = 4           # equal-length items of fewer than PROBE_SHORT_BELOW frames

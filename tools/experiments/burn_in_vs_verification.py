@@ -1,4 +1,4 @@
-"""Do the clips that fail verification (noisy / over-reaching targets: 16-22 solves on every frame) verify with a longer burn-in?
+"""Do the clips that fail verification (it turns out: the wound-up ones, ~12 solves on every frame, easy and hard clips alike) verify with a longer burn-in?
 256 distinct 3000-frame clips, half of them hard; chunks of 512 and 256 with burn-in 24 ... 384; per-kind re-solved frames."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

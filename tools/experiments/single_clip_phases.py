@@ -2,7 +2,7 @@
 
 Measured (round 3, one MI355X, chunk 16 / burn-in 24, 188 chunks): total 1.68 ms (easy clip) / 2.15 ms (hard) = host plan 0.07 + launch 1
 1.32 / 1.80 + walk 0.26 (1.4 us per boundary when every chunk verifies; a re-solved chunk adds its 16 frames, ~0.45 ms).  Launch 1 lasts as long
-as its SLOWEST chunk -- 40 frames at one wavefront's latency, more where a stretch runs the full solve budget (bench.py's clips: 3.2 ms in all) --
+as its SLOWEST chunk -- 40 frames at one wavefront's latency, more where a stretch needs twice the usual solves (bench.py's clips: 3.2 ms in all) --
 so what is left is per-solve latency, not the walk: checking all boundaries in parallel would save at most the 0.26 ms."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
