@@ -931,3 +931,53 @@ def test_launch_order_by_probe_moves_work_in_time_only():
     q3, _, _ = eng.ik_solve(pos, quat, sc, short, launch_order=eng.plan_order(pos, quat, sc, short))
     q4, _, _ = eng.ik_solve(pos, quat, sc, short, launch_order=None)
     assert torch.equal(q3[:40], q4[:40])
+
+
+def test_handles_on_concurrent_host_threads():
+    """include/gmr_amd.h: one handle per host thread at a time, different handles are independent.  Four host threads, each with its own
+    handle and stream, solve, run FK and the kin_ops and parse BVH text at the same time, twenty rounds each; every result equals the serial one
+    (the library's shared state is the per-device scratch pool behind a mutex and nothing else)."""
+    import threading
+    from gmr_amd.engine import Engine
+    cm = compiled("smplx", "unitree_g1")
+    dev = torch.device("cuda", 0)
+    n_thr, rounds = 4, 20
+    sets = []
+    for k in range(n_thr):
+        pos, quat, names, offs, _ = synth.synth_clips(cm, 6 + k, 40 + 8 * k, seed=300 + k, hard=bool(k % 2), dtype=np.float32)
+        sets.append((torch.from_numpy(pos).to(dev), torch.from_numpy(quat).to(dev), cm.slot_columns(names), make_items(offs)))
+    ref_eng = Engine(cm)
+    refs = []
+    for p, q, sc, items in sets:
+        out, it, _ = ref_eng.ik_solve(p, q, sc, items)
+        d32 = out[:, 7:].float().contiguous()
+        bp, br = ref_eng.fk(out[:, :3].float().contiguous(), out[:, [4, 5, 6, 3]].float().contiguous(), d32)
+        refs.append((out.clone(), it.clone(), bp.clone(), br.clone(), ref_eng.dof_to_rot(d32).clone()))
+    torch.cuda.synchronize()
+    errors = []
+
+    def work(k):
+        try:
+            eng = Engine(cm)
+            st = torch.cuda.Stream(dev)
+            p, q, sc, items = sets[k]
+            with torch.cuda.stream(st):
+                for _ in range(rounds):
+                    out, it, _ = eng.ik_solve(p, q, sc, items)
+                    d32 = out[:, 7:].float().contiguous()
+                    bp, br = eng.fk(out[:, :3].float().contiguous(), out[:, [4, 5, 6, 3]].float().contiguous(), d32)
+                    jr = eng.dof_to_rot(d32)
+                    st.synchronize()
+                    r = refs[k]
+                    if not (torch.equal(out, r[0]) and torch.equal(it, r[1]) and torch.equal(bp, r[2]) and torch.equal(br, r[3]) and torch.equal(jr, r[4])):
+                        errors.append(f"thread {k}: results differ from the serial run")
+                        return
+            eng.close()
+        except Exception as ex:  # noqa: BLE001
+            errors.append(f"thread {k}: {ex!r}")
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(n_thr)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors and not any(t.is_alive() for t in threads), errors
