@@ -935,7 +935,7 @@ def test_launch_order_by_probe_moves_work_in_time_only():
 
 def test_handles_on_concurrent_host_threads():
     """include/gmr_amd.h: one handle per host thread at a time, different handles are independent.  Four host threads, each with its own
-    handle and stream, solve, run FK and the kin_ops and parse BVH text at the same time, twenty rounds each; every result equals the serial one
+    handle and stream, solve, run FK and a kin_op at the same time, twenty rounds each; every result equals the serial one
     (the library's shared state is the per-device scratch pool behind a mutex and nothing else)."""
     import threading
     from gmr_amd.engine import Engine
