@@ -1,4 +1,4 @@
-"""IK throughput of every config robot (BASELINE config 4's robots + the hands model): 2048 clips x 300 frames each."""
+"""IK throughput of every registry robot with an SMPL-X config: 8192 clips x 600 frames each (64 distinct clips tiled, half of them hard); `core` != 0: the structured QP back end applies."""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,9 +9,11 @@ from gmr_amd.model import compile_model
 from gmr_amd.engine import Engine
 from gmr_amd.schedule import make_items
 
-S, T, D = 2048, 300, 32
+S, T, D = 8192, 600, 64
 rows = []
-for robot in ["unitree_g1", "unitree_g1_with_hands", "booster_t1", "stanford_toddy", "fourier_n1", "engineai_pm01"]:
+ROBOTS = sys.argv[1:] or ["unitree_g1", "unitree_g1_with_hands", "booster_t1", "stanford_toddy", "fourier_n1", "engineai_pm01", "kuavo_s45", "hightorque_hi",
+                         "galaxea_r1pro", "booster_k1"]  # (berkeley_humanoid_lite: the registry names smplx_to_bhl.json, which the reference does not ship)
+for robot in ROBOTS:
     cm = compile_model(load_robot(params.ROBOT_XML_DICT[robot], name=robot), load_ik_config(params.IK_CONFIG_DICT["smplx"][robot]))
     eng = Engine(cm, 0)
     pe, qe, names, _, _ = synth.synth_clips(cm, D // 2, T, seed=1, hard=False, dtype=np.float32)
